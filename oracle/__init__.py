@@ -1,0 +1,176 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for
+  * ``librm_restate.so``  -- our plain-C CPU restatement of the reference render
+    path (oracle/rm_restate.c), buildable anywhere, and
+  * ``_ref/libref_oracle.so`` -- the UNMODIFIED reference kernel compiled for
+    x86-64 (oracle/Makefile `ref`), only buildable where /root/reference exists.
+
+Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+bench.py may import this package.  The product package (raymarchcl_amd) never
+does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE_CL = "/root/reference/resources/renderer.cl"
+TABLE_FLOATS = 0x4000 * 4
+OPTS_SIZE = 544
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        (n, ctypes.c_uint64)
+        for n in (
+            "vox_reads",
+            "mc_reads",
+            "rays",
+            "dts_calls",
+            "march_steps",
+            "ao_calls",
+            "primary_hits",
+            "oob_material",
+        )
+    ]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(ref=None):
+    """Compile the restatement (always) and the reference build (when the
+    reference tree is present, or when ``ref=True`` is forced)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "restate"])
+    if ref is None:
+        ref = os.path.exists(REFERENCE_CL)
+    if ref:
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_restate = None
+_refs = {}
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+def restate_lib():
+    global _restate
+    if _restate is None:
+        path = os.path.join(HERE, "librm_restate.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        lib = ctypes.CDLL(path)
+        lib.rmo_render_image.argtypes = [_u8p, _f32p, ctypes.c_void_p, _f32p, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(Stats)]
+        lib.rmo_render_image.restype = None
+        lib.rmo_tonemap_image.argtypes = [_f32p, ctypes.c_void_p, _u32p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int]
+        lib.rmo_tonemap_image.restype = None
+        lib.rmo_render_frame.argtypes = [_u8p, ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, _u32p,
+                                         ctypes.c_int, ctypes.c_int, ctypes.POINTER(Stats)]
+        lib.rmo_render_frame.restype = None
+        lib.rmo_hw_threads.restype = ctypes.c_int
+        for name in ("rmo_exp", "rmo_exp2"):
+            getattr(lib, name).argtypes = [ctypes.c_float]
+            getattr(lib, name).restype = ctypes.c_float
+        lib.rmo_pow.argtypes = [ctypes.c_float, ctypes.c_float]
+        lib.rmo_pow.restype = ctypes.c_float
+        lib.rmo_f2i.argtypes = [ctypes.c_float]
+        lib.rmo_f2i.restype = ctypes.c_int32
+        lib.rmo_f2u.argtypes = [ctypes.c_float]
+        lib.rmo_f2u.restype = ctypes.c_uint32
+        lib.rmo_convert_int_sat.argtypes = [ctypes.c_float]
+        lib.rmo_convert_int_sat.restype = ctypes.c_int32
+        _restate = lib
+    return _restate
+
+
+def have_ref(fma=False):
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_oracle_fma.so" if fma else "libref_oracle.so"))
+
+
+def ref_lib(fma=False):
+    if fma not in _refs:
+        path = os.path.join(HERE, "_ref", "libref_oracle_fma.so" if fma else "libref_oracle.so")
+        lib = ctypes.CDLL(path)
+        lib.ref_render_image.argtypes = [_u8p, _f32p, ctypes.c_void_p, _f32p, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int]
+        lib.ref_render_image.restype = None
+        lib.ref_tonemap_image.argtypes = [_f32p, ctypes.c_void_p, _u32p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int]
+        lib.ref_tonemap_image.restype = None
+        _refs[fma] = lib
+    return _refs[fma]
+
+
+def _check(vox, mc, opts, pixels):
+    assert vox.dtype == np.uint8 and vox.flags.c_contiguous
+    assert mc.dtype == np.float32 and mc.flags.c_contiguous
+    assert pixels.dtype == np.float32 and pixels.flags.c_contiguous
+    assert len(opts) % OPTS_SIZE == 0
+
+
+def render_image(vox, mc, opts, pixels, n=None, id0=0, id1=None, threads=0, stats=None):
+    """Restatement of one RenderImage pass, in place on ``pixels`` (n*4 float32)."""
+    _check(vox, mc, opts, pixels)
+    n = pixels.size // 4 if n is None else n
+    id1 = n if id1 is None else id1
+    ob = ctypes.create_string_buffer(bytes(opts), OPTS_SIZE)
+    restate_lib().rmo_render_image(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p), n,
+                                   id0, id1, threads,
+                                   ctypes.byref(stats) if stats is not None else None)
+    return pixels
+
+
+def tonemap_image(pixels, opts, n=None):
+    n = pixels.size // 4 if n is None else n
+    argb = np.zeros(n, dtype=np.uint32)
+    ob = ctypes.create_string_buffer(bytes(opts)[:OPTS_SIZE], OPTS_SIZE)
+    restate_lib().rmo_tonemap_image(_ptr(pixels, _f32p), ob, _ptr(argb, _u32p), n, 0, n)
+    return argb
+
+
+def render_frame(vox, opts_array, mc_array, n, threads=0, stats=None, tonemap=True):
+    """Restatement of the whole pipeline.  opts_array: iter*544 bytes;
+    mc_array: float32 [iter, 0x4000*4].  -> (pixels float32[n*4], argb uint32[n] | None)"""
+    iters = len(opts_array) // OPTS_SIZE
+    mc_array = np.ascontiguousarray(mc_array, dtype=np.float32).reshape(-1)
+    assert mc_array.size == iters * TABLE_FLOATS
+    pixels = np.zeros(n * 4, dtype=np.float32)
+    argb = np.zeros(n, dtype=np.uint32) if tonemap else None
+    ob = ctypes.create_string_buffer(bytes(opts_array), len(opts_array))
+    restate_lib().rmo_render_frame(_ptr(vox, _u8p), ob, _ptr(mc_array, _f32p), iters,
+                                   _ptr(pixels, _f32p),
+                                   _ptr(argb, _u32p) if tonemap else None, n, threads,
+                                   ctypes.byref(stats) if stats is not None else None)
+    return pixels, argb
+
+
+def ref_render_image(vox, mc, opts, pixels, n=None, id0=0, id1=None, fma=False):
+    """The reference kernel itself (x86 build), in place on ``pixels``."""
+    _check(vox, mc, opts, pixels)
+    n = pixels.size // 4 if n is None else n
+    id1 = n if id1 is None else id1
+    ob = ctypes.create_string_buffer(bytes(opts), OPTS_SIZE)
+    ref_lib(fma).ref_render_image(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p), n,
+                                  id0, id1)
+    return pixels
+
+
+def ref_tonemap_image(pixels, opts, n=None, fma=False):
+    n = pixels.size // 4 if n is None else n
+    argb = np.zeros(n, dtype=np.uint32)
+    ob = ctypes.create_string_buffer(bytes(opts)[:OPTS_SIZE], OPTS_SIZE)
+    ref_lib(fma).ref_tonemap_image(_ptr(pixels, _f32p), ob, _ptr(argb, _u32p), n, 0, n)
+    return argb

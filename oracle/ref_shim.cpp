@@ -1,0 +1,89 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE (not product code).
+//
+// Links the UNMODIFIED reference kernel object (clang -x cl of
+// /root/reference/resources/renderer.cl, built by oracle/Makefile into
+// oracle/_ref/) into a host shared library:
+//   * supplies the 22 OpenCL C built-ins the object leaves undefined, as thin
+//     vector wrappers over the scalar semantics in oracle/cl_scalar.h
+//     (OpenCL 1.2 spec definitions; see that header for why a shim is needed),
+//   * supplies get_global_id() from a thread-local, and
+//   * exports a C entry point that runs the reference's RenderImage /
+//     TonemapImage (renderer.cl:478-508) for a range of work-item ids, which
+//     is what an OpenCL CPU device's NDRange would do.
+//
+// Must be compiled with clang++ (ext_vector_type mangling == OpenCL floatN)
+// and -ffp-contract=off.  No <cmath>: the global names exp/pow/sqrt/... are
+// defined here with OpenCL's C++-mangled signatures.
+#include <stddef.h>
+#include <stdint.h>
+#include "cl_scalar.h"
+
+typedef float f3 __attribute__((ext_vector_type(3)));
+typedef int i3 __attribute__((ext_vector_type(3)));
+
+static thread_local size_t tl_gid = 0;
+#define SHIM __attribute__((visibility("hidden")))
+
+SHIM size_t get_global_id(unsigned) { return tl_gid; }
+
+SHIM f3 convert_float3(i3 v) { return (f3){(float)v.x, (float)v.y, (float)v.z}; }
+SHIM i3 convert_int3_sat(f3 v) {
+  return (i3){cl_convert_int_sat(v.x), cl_convert_int_sat(v.y), cl_convert_int_sat(v.z)};
+}
+SHIM float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SHIM float exp(float x) { return cl_exp(x); }
+SHIM float exp2(float x) { return cl_exp2(x); }
+SHIM float pow(float x, float y) { return cl_pow(x, y); }
+SHIM float fabs(float x) { return cl_fabs(x); }
+SHIM float sqrt(float x) { return cl_sqrt(x); }
+SHIM float mad(float a, float b, float c) { return cl_mad(a, b, c); }
+SHIM f3 mad(f3 a, f3 b, f3 c) {
+  return (f3){cl_mad(a.x, b.x, c.x), cl_mad(a.y, b.y, c.y), cl_mad(a.z, b.z, c.z)};
+}
+SHIM float max(float a, float b) { return cl_max(a, b); }
+SHIM f3 max(f3 a, f3 b) { return (f3){cl_max(a.x, b.x), cl_max(a.y, b.y), cl_max(a.z, b.z)}; }
+SHIM float min(float a, float b) { return cl_min(a, b); }
+SHIM f3 min(f3 a, f3 b) { return (f3){cl_min(a.x, b.x), cl_min(a.y, b.y), cl_min(a.z, b.z)}; }
+SHIM f3 mix(f3 a, f3 b, f3 t) {
+  return (f3){cl_mix(a.x, b.x, t.x), cl_mix(a.y, b.y, t.y), cl_mix(a.z, b.z, t.z)};
+}
+SHIM f3 mix(f3 a, f3 b, float t) {
+  return (f3){cl_mix(a.x, b.x, t), cl_mix(a.y, b.y, t), cl_mix(a.z, b.z, t)};
+}
+SHIM float step(float e, float x) { return cl_step(e, x); }
+SHIM float clamp(float x, float lo, float hi) { return cl_clamp(x, lo, hi); }
+SHIM f3 cross(f3 a, f3 b) {
+  return (f3){a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+SHIM float length(f3 v) { return cl_sqrt(dot(v, v)); }
+SHIM f3 normalize(f3 v) {
+  if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
+  const float s = 1.0f / cl_sqrt(dot(v, v));
+  return (f3){v.x * s, v.y * s, v.z * s};
+}
+
+// The two reference kernels (C linkage in the .cl object).
+extern "C" {
+SHIM void RenderImage(const unsigned char* voxels, const void* mcSamples, const void* opts,
+                      void* pixels, int n);
+SHIM void TonemapImage(const void* pixels, void* opts, unsigned* rgba, int n);
+
+// Run work-items id0 <= id < id1 of RenderImage on the calling thread.
+__attribute__((visibility("default"))) void ref_render_image(
+    const unsigned char* voxels, const float* mc, const void* opts544, float* pixels, int n,
+    int id0, int id1) {
+  for (int id = id0; id < id1; ++id) {
+    tl_gid = (size_t)id;
+    RenderImage(voxels, mc, opts544, pixels, n);
+  }
+}
+__attribute__((visibility("default"))) void ref_tonemap_image(const float* pixels,
+                                                              const void* opts544,
+                                                              uint32_t* argb, int n, int id0,
+                                                              int id1) {
+  for (int id = id0; id < id1; ++id) {
+    tl_gid = (size_t)id;
+    TonemapImage(pixels, (void*)opts544, argb, n);
+  }
+}
+}
