@@ -1,0 +1,122 @@
+/*
+ * raymarch_hip.h -- C ABI of libraymarch_hip.so: the MI355X (gfx950) drop-in
+ * for the host<->device boundary of thi-ng/raymarchcl's render path.
+ *
+ * In the reference the Clojure host hands five buffers and a declarative step
+ * list to thi.ng.simplecl (core.clj:76-97, 119-148), which issues
+ * clEnqueueWriteBuffer / clEnqueueNDRangeKernel(RenderImage | TonemapImage) /
+ * clEnqueueReadBuffer.  Each entry point below names the reference interface
+ * it replaces.  Conventions:
+ *   - plain pointers and sizes only; host buffers are borrowed for the call;
+ *   - `opts544` is the reference's TRenderOpts record exactly as
+ *     thi.ng/structgen encodes it (renderer.cl:35-78; 544 bytes, little-endian,
+ *     OpenCL alignment) -- `opts_array` is `iter` of them back to back;
+ *   - `mc` is one scatter table: 0x4000 float4 (generators.clj:8-16);
+ *     `mc_array` is `iter` tables back to back;
+ *   - `pixels` is the float4 accumulator p-buf (core.clj:144), `argb` the
+ *     packed 0xAARRGGBB q-buf (core.clj:145);
+ *   - every function returns RM_OK (0) or a negative RM_E* code; the message
+ *     is available from rm_last_error() (thread local).  Nothing throws.
+ *   - one rm_ctx is used by one thread at a time (the reference is a
+ *     single-threaded REPL with one in-order queue); contexts are independent.
+ *   - there is no CPU fallback: without a gfx950 device rm_create fails.
+ */
+#ifndef RAYMARCH_HIP_H
+#define RAYMARCH_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_OK 0
+#define RM_EINVAL (-1)   /* bad argument */
+#define RM_EDEVICE (-2)  /* HIP runtime / device error */
+#define RM_ESTATE (-3)   /* call order (e.g. render before rm_set_volume) */
+
+#define RM_OPTS_BYTES 544
+#define RM_TABLE_FLOATS (0x4000 * 4)
+
+typedef struct rm_ctx rm_ctx;
+
+/* Event counters of the render kernels (filled only by the *_counted calls);
+ * vox_reads and mc_reads define the algorithmic bytes of a frame. */
+typedef struct rm_counters {
+  uint64_t vox_reads;    /* in-bounds voxel byte loads the algorithm performs */
+  uint64_t mc_reads;     /* scatter table float4 loads */
+  uint64_t rays;         /* outer marches (primary + shadow + reflection) */
+  uint64_t dts_calls;    /* distance estimates */
+  uint64_t march_steps;  /* fixed-step samples */
+  uint64_t ao_calls;
+  uint64_t primary_hits;
+  uint64_t oob_material; /* material index outside the record: undefined in the reference */
+} rm_counters;
+
+const char* rm_last_error(void);
+int rm_abi_version(void);
+/* number of visible HIP devices (0 when there is none / no driver) */
+int rm_device_count(void);
+
+/* cl/select-platform + max-device + make-context + init-state with the
+ * compiled program (core.clj:121-128).  device_id: HIP ordinal. */
+int rm_create(int device_id, rm_ctx** out);
+void rm_destroy(rm_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the context's own stream; NULL restores the internal one. */
+int rm_set_stream(rm_ctx* ctx, void* hip_stream);
+int rm_synchronize(rm_ctx* ctx);
+
+/* v-buf: vio/load-volume wraps the bytes into a read-only buffer that the
+ * pipeline's first step writes to the device (io.clj:29-33, core.clj:81,146).
+ * The volume is copied into HBM and stays resident until replaced. */
+int rm_set_volume(rm_ctx* ctx, const uint8_t* voxels, int rx, int ry, int rz);
+/* Same, but the bytes already live in device memory owned by the caller
+ * (borrowed until the next rm_set_volume* / rm_destroy). */
+int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int rz);
+
+/* One NDRange of the RenderImage kernel (renderer.cl:478-494; pipeline step
+ * core.clj:84-89): write opts + table, run work-items 0..n-1, read the
+ * accumulator back.  `pixels` is in/out (n float4). */
+int rm_render_image(rm_ctx* ctx, const float* mc, const void* opts544, float* pixels, int n);
+/* Same for work-items id0 <= id < id1 only (what a tile of the NDRange does). */
+int rm_render_image_range(rm_ctx* ctx, const float* mc, const void* opts544, float* pixels, int n,
+                          int id0, int id1);
+/* As rm_render_image, additionally ADDS the kernel's event counts to *out. */
+int rm_render_image_counted(rm_ctx* ctx, const float* mc, const void* opts544, float* pixels,
+                            int n, rm_counters* out);
+
+/* One NDRange of the TonemapImage kernel (renderer.cl:496-508; core.clj:91-97). */
+int rm_tonemap_image(rm_ctx* ctx, const float* pixels, const void* opts544, uint32_t* argb, int n);
+
+/* ops/execute-pipeline of the pipeline built by make-pipeline (core.clj:76-97,
+ * 171): accumulator zeroed, `iter` RenderImage passes in order with
+ * (opts_i, mc_i), TonemapImage with opts_0, read back.  pixels_out (n float4)
+ * and argb_out (n uint32) may each be NULL. */
+int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, int iter, int n,
+                    float* pixels_out, uint32_t* argb_out);
+
+/* ---- device-resident form of the same pipeline (inputs already in HBM) ----
+ * d_opts: iter*544 bytes, d_mc: iter tables, d_pixels: n float4 (out),
+ * d_argb: n uint32 (out, nullable).  Asynchronous on the context's stream.
+ * Only the image tiles t (8x8 pixels, row-major tile order) with
+ * t % tile_stride == tile_first are rendered and written -- (0,1) renders
+ * everything; (rank, world) is the multi-GPU partition. */
+int rm_frame_device(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
+                    int tile_first, int tile_stride, float* d_pixels, uint32_t* d_argb);
+
+/* Elapsed milliseconds of the render kernels of the last rm_frame_device /
+ * rm_render_frame call, measured with HIP events on the stream they ran on
+ * (synchronises).  launches = number of kernel launches in that interval. */
+int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
+
+/* Device-vs-host checks of the float primitives the parity contract rests on.
+ * op: 0 a/b, 1 sqrt(a), 2 exp(a), 3 exp2(a), 4 pow(a,b), 5 (int)a [x86],
+ *     6 (uint)a [x86], 7 convert_int_sat(a), 8 a*b+c unfused (c = a).
+ * a, b: n floats (b may be NULL for unary ops); out: n 32-bit words. */
+int rm_selftest_prims(rm_ctx* ctx, int op, const float* a, const float* b, uint32_t* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

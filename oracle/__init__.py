@@ -74,6 +74,8 @@ def restate_lib():
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(Stats)]
         lib.rmo_render_image.restype = None
+        lib.rmo_render_image_masked.argtypes = lib.rmo_render_image.argtypes + [_u8p]
+        lib.rmo_render_image_masked.restype = None
         lib.rmo_tonemap_image.argtypes = [_f32p, ctypes.c_void_p, _u32p, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int]
         lib.rmo_tonemap_image.restype = None
@@ -121,15 +123,24 @@ def _check(vox, mc, opts, pixels):
     assert len(opts) % OPTS_SIZE == 0
 
 
-def render_image(vox, mc, opts, pixels, n=None, id0=0, id1=None, threads=0, stats=None):
-    """Restatement of one RenderImage pass, in place on ``pixels`` (n*4 float32)."""
+def render_image(vox, mc, opts, pixels, n=None, id0=0, id1=None, threads=0, stats=None,
+                 undefined_mask=None):
+    """Restatement of one RenderImage pass, in place on ``pixels`` (n*4 float32).
+    ``undefined_mask`` (uint8[n], optional) gets 1 where the reference's
+    behaviour is undefined (out-of-record material index)."""
     _check(vox, mc, opts, pixels)
     n = pixels.size // 4 if n is None else n
     id1 = n if id1 is None else id1
     ob = ctypes.create_string_buffer(bytes(opts), OPTS_SIZE)
-    restate_lib().rmo_render_image(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p), n,
-                                   id0, id1, threads,
-                                   ctypes.byref(stats) if stats is not None else None)
+    sp = ctypes.byref(stats) if stats is not None else None
+    if undefined_mask is None:
+        restate_lib().rmo_render_image(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p),
+                                       n, id0, id1, threads, sp)
+    else:
+        assert undefined_mask.dtype == np.uint8 and undefined_mask.size >= n
+        restate_lib().rmo_render_image_masked(_ptr(vox, _u8p), _ptr(mc, _f32p), ob,
+                                              _ptr(pixels, _f32p), n, id0, id1, threads, sp,
+                                              _ptr(undefined_mask, _u8p))
     return pixels
 
 

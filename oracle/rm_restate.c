@@ -466,8 +466,9 @@ int rmo_hw_threads(void) {
 
 /* RenderImage for work-items id0 <= id < id1 (id < n as in the kernel guard).
  * threads <= 0: all hardware threads.  stats (nullable) is ADDED to. */
-void rmo_render_image(const uint8_t* vox, const float* mc, const void* opts544, float* pixels,
-                      int n, int id0, int id1, int threads, rmo_stats* stats) {
+static void render_image_impl(const uint8_t* vox, const float* mc, const void* opts544,
+                              float* pixels, int n, int id0, int id1, int threads,
+                              rmo_stats* stats, uint8_t* undefined_mask) {
   if (id1 > n) id1 = n;
   if (id0 < 0) id0 = 0;
 #ifdef _OPENMP
@@ -482,11 +483,29 @@ void rmo_render_image(const uint8_t* vox, const float* mc, const void* opts544, 
     ctx_t c;
     ctx_init(&c, vox, mc, opts544);
 #pragma omp for schedule(dynamic, 64)
-    for (int id = id0; id < id1; id++) render_one(&c, pixels, id);
+    for (int id = id0; id < id1; id++) {
+      const uint64_t before = c.st.oob_material;
+      render_one(&c, pixels, id);
+      if (undefined_mask && c.st.oob_material != before) undefined_mask[id] = 1;
+    }
 #pragma omp critical
     stats_add(&total, &c.st);
   }
   if (stats) stats_add(stats, &total);
+}
+
+void rmo_render_image(const uint8_t* vox, const float* mc, const void* opts544, float* pixels,
+                      int n, int id0, int id1, int threads, rmo_stats* stats) {
+  render_image_impl(vox, mc, opts544, pixels, n, id0, id1, threads, stats, NULL);
+}
+/* Same; additionally sets undefined_mask[id] = 1 for every work-item that
+ * indexed materials[] outside the option record -- behaviour the reference
+ * leaves undefined (it reads whatever follows its private copy on the stack),
+ * so such samples are excluded from parity statements. */
+void rmo_render_image_masked(const uint8_t* vox, const float* mc, const void* opts544,
+                             float* pixels, int n, int id0, int id1, int threads,
+                             rmo_stats* stats, uint8_t* undefined_mask) {
+  render_image_impl(vox, mc, opts544, pixels, n, id0, id1, threads, stats, undefined_mask);
 }
 
 /* TonemapImage: renderer.cl:448-454, 496-508 */

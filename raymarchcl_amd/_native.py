@@ -1,0 +1,226 @@
+"""ctypes binding of libraymarch_hip.so (include/raymarch_hip.h).
+
+There is deliberately no fallback: if the library has not been built, cannot
+be loaded, or no gfx950 device is visible, the calls raise.  The oracle under
+/oracle is never imported from here.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libraymarch_hip.so")
+SOURCES = ["rm_kernels.hip", "rm_api.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+OPTS_BYTES = 544
+TABLE_FLOATS = 0x4000 * 4
+
+# every symbol include/raymarch_hip.h declares
+EXPORTS = [
+    "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_destroy",
+    "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
+    "rm_render_frame", "rm_frame_device", "rm_last_frame_timing", "rm_selftest_prims",
+]
+
+
+class RmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libraymarch_hip: {msg} (code {code})")
+        self.code = code
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in (
+        "vox_reads", "mc_reads", "rays", "dts_calls", "march_steps", "ao_calls", "primary_hits",
+        "oob_material")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    files.append(os.path.join(HERE, "..", "include", "raymarch_hip.h"))
+    return any(os.path.getmtime(f) > t for f in files if os.path.isfile(f))
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RmError(-2, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = ctypes.CDLL(LIB_PATH)
+    L.rm_last_error.restype = ctypes.c_char_p
+    L.rm_create.argtypes = [_i, ctypes.POINTER(_vp)]
+    L.rm_destroy.argtypes = [_vp]
+    L.rm_destroy.restype = None
+    L.rm_set_stream.argtypes = [_vp, _vp]
+    L.rm_synchronize.argtypes = [_vp]
+    L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
+    L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
+    L.rm_render_image.argtypes = [_vp, _vp, _vp, _vp, _i]
+    L.rm_render_image_range.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i]
+    L.rm_render_image_counted.argtypes = [_vp, _vp, _vp, _vp, _i, ctypes.POINTER(Counters)]
+    L.rm_tonemap_image.argtypes = [_vp, _vp, _vp, _vp, _i]
+    L.rm_render_frame.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
+    L.rm_frame_device.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]
+    L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
+    L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RmError(rc, lib().rm_last_error().decode("utf-8", "replace"))
+
+
+def _np(a, dtype, name):
+    if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags.c_contiguous:
+        raise TypeError(f"{name} must be a C-contiguous numpy array of {np.dtype(dtype).name}")
+    return a.ctypes.data
+
+
+class Context:
+    """Owns one rm_ctx (one device, one stream)."""
+
+    def __init__(self, device_id=0):
+        self._h = _vp()
+        check(lib().rm_create(device_id, ctypes.byref(self._h)))
+        self.device_id = device_id
+        self.vres = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- volume -----------------------------------------------------------
+    def set_volume(self, vox, vres):
+        rx, ry, rz = (int(v) for v in vres)
+        p = _np(vox, np.uint8, "vox")
+        if vox.size != rx * ry * rz:
+            raise ValueError(f"volume has {vox.size} bytes, vres says {rx}x{ry}x{rz}")
+        check(lib().rm_set_volume(self._h, p, rx, ry, rz))
+        self.vres = (rx, ry, rz)
+
+    def set_volume_device(self, dptr, vres):
+        rx, ry, rz = (int(v) for v in vres)
+        check(lib().rm_set_volume_device(self._h, dptr, rx, ry, rz))
+        self.vres = (rx, ry, rz)
+
+    def set_stream(self, stream_ptr):
+        check(lib().rm_set_stream(self._h, stream_ptr))
+
+    def synchronize(self):
+        check(lib().rm_synchronize(self._h))
+
+    # -- kernel-level entry points (host buffers) -------------------------
+    @staticmethod
+    def _opts(opts, count=1):
+        b = bytes(opts)
+        if len(b) != OPTS_BYTES * count:
+            raise ValueError(f"opts must be {OPTS_BYTES * count} bytes, got {len(b)}")
+        return ctypes.create_string_buffer(b, len(b))
+
+    def render_image(self, mc, opts, pixels, n=None, id0=None, id1=None, counters=None):
+        n = pixels.size // 4 if n is None else n
+        pm = _np(mc, np.float32, "mc")
+        if mc.size != TABLE_FLOATS:
+            raise ValueError("mc must hold 0x4000 float4")
+        pp = _np(pixels, np.float32, "pixels")
+        if pixels.size < 4 * n:
+            raise ValueError("pixels too small")
+        ob = self._opts(opts)
+        if counters is not None:
+            check(lib().rm_render_image_counted(self._h, pm, ob, pp, n, ctypes.byref(counters)))
+        elif id0 is None and id1 is None:
+            check(lib().rm_render_image(self._h, pm, ob, pp, n))
+        else:
+            check(lib().rm_render_image_range(self._h, pm, ob, pp, n, id0 or 0,
+                                              n if id1 is None else id1))
+        return pixels
+
+    def tonemap_image(self, pixels, opts, n=None):
+        n = pixels.size // 4 if n is None else n
+        argb = np.zeros(n, dtype=np.uint32)
+        check(lib().rm_tonemap_image(self._h, _np(pixels, np.float32, "pixels"),
+                                     self._opts(bytes(opts)[:OPTS_BYTES]), argb.ctypes.data, n))
+        return argb
+
+    def render_frame(self, opts_array, mc_array, n, want_pixels=True, want_argb=True):
+        iters = len(bytes(opts_array)) // OPTS_BYTES
+        mc_array = np.ascontiguousarray(mc_array, dtype=np.float32).reshape(-1)
+        if mc_array.size != iters * TABLE_FLOATS:
+            raise ValueError("mc_array must hold one table per pass")
+        pixels = np.zeros(4 * n, dtype=np.float32) if want_pixels else None
+        argb = np.zeros(n, dtype=np.uint32) if want_argb else None
+        check(lib().rm_render_frame(self._h, self._opts(opts_array, iters), mc_array.ctypes.data,
+                                    iters, n,
+                                    pixels.ctypes.data if want_pixels else None,
+                                    argb.ctypes.data if want_argb else None))
+        return pixels, argb
+
+    # -- device-resident pipeline ----------------------------------------
+    def frame_device(self, d_opts, d_mc, iters, n, d_pixels, d_argb=None, tile_first=0,
+                     tile_stride=1):
+        check(lib().rm_frame_device(self._h, d_opts, d_mc, iters, n, tile_first, tile_stride,
+                                    d_pixels, d_argb))
+
+    def last_frame_timing(self):
+        ms = ctypes.c_float()
+        k = _i()
+        check(lib().rm_last_frame_timing(self._h, ctypes.byref(ms), ctypes.byref(k)))
+        return float(ms.value), int(k.value)
+
+    def selftest_prims(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.zeros(a.size, dtype=np.uint32)
+        pb = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            pb = b.ctypes.data
+        check(lib().rm_selftest_prims(self._h, op, a.ctypes.data, pb, out.ctypes.data, a.size))
+        return out
+
+
+def device_count():
+    return int(lib().rm_device_count())

@@ -1,0 +1,380 @@
+// rm_api.hip -- the C ABI declared in include/raymarch_hip.h.
+//
+// Replaces what thi.ng.simplecl does for the reference host (context, queue,
+// buffers, the compiled pipeline of core.clj:76-97): device buffers live in an
+// rm_ctx, every call validates its arguments, converts HIP errors into return
+// codes + a thread-local message, and never throws across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/raymarch_hip.h"
+#include "rm_kernels.h"
+#include "rm_shade.hpp"
+
+static_assert(sizeof(rm_counters) == sizeof(rmk::Counters), "counter structs must match");
+static_assert(RM_OPTS_BYTES == RM_OPTS_SIZE, "option record size");
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(RM_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct rm_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
+  DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, cnt_buf, prim_a, prim_b, prim_o;
+  int rx = 0, ry = 0, rz = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int launches = 0;
+};
+
+namespace {
+
+int check_ctx(rm_ctx* c) {
+  if (!c) return fail(RM_EINVAL, "rm_ctx is NULL");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(RM_EDEVICE, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+  return RM_OK;
+}
+
+// The record's own fields must be usable before a kernel trusts them.
+int check_opts(rm_ctx* c, const void* opts544, int n) {
+  RmOpts o;
+  memcpy(&o, opts544, sizeof o);
+  if (o.resolution[0] <= 0 || o.resolution[1] <= 0)
+    return fail(RM_EINVAL, "TRenderOpts.resolution = (%d,%d)", o.resolution[0], o.resolution[1]);
+  if (o.voxelRes[0] != c->rx || o.voxelRes[1] != c->ry || o.voxelRes[2] != c->rz ||
+      o.voxelRes[3] != c->rx * c->ry)
+    return fail(RM_EINVAL, "TRenderOpts.voxelRes = (%d,%d,%d,%d) does not match the volume %dx%dx%d",
+                o.voxelRes[0], o.voxelRes[1], o.voxelRes[2], o.voxelRes[3], c->rx, c->ry, c->rz);
+  if (o.numLights > 4) return fail(RM_EINVAL, "TRenderOpts.numLights = %d (max 4)", (int)o.numLights);
+  if (n < 0) return fail(RM_EINVAL, "n = %d", n);
+  return RM_OK;
+}
+
+int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n, int id0,
+                     int id1, rm_counters* counters) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!mc || !opts544 || (!pixels && n > 0)) return fail(RM_EINVAL, "NULL buffer");
+  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  rc = check_opts(c, opts544, n);
+  if (rc) return rc;
+  if (n == 0) return RM_OK;
+  const size_t pix_bytes = (size_t)n * 16;
+  HIP_TRY(c->mc_buf.reserve(RM_TABLE_FLOATS * 4));
+  HIP_TRY(c->opts_buf.reserve(RM_OPTS_BYTES));
+  HIP_TRY(c->pix_buf.reserve(pix_bytes));
+  HIP_TRY(hipMemcpyAsync(c->mc_buf.p, mc, RM_TABLE_FLOATS * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts544, RM_OPTS_BYTES, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pix_buf.p, pixels, pix_bytes, hipMemcpyHostToDevice, c->stream));
+  rmk::Counters* d_cnt = nullptr;
+  if (counters) {
+    HIP_TRY(c->cnt_buf.reserve(sizeof(rmk::Counters)));
+    HIP_TRY(hipMemsetAsync(c->cnt_buf.p, 0, sizeof(rmk::Counters), c->stream));
+    d_cnt = static_cast<rmk::Counters*>(c->cnt_buf.p);
+  }
+  RmOpts o;
+  memcpy(&o, opts544, sizeof o);
+  HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, static_cast<const float*>(c->mc_buf.p),
+                                  static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
+                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, d_cnt));
+  HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
+  rm_counters got{};
+  if (counters)
+    HIP_TRY(hipMemcpyAsync(&got, c->cnt_buf.p, sizeof got, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (counters) {
+    uint64_t* dst = reinterpret_cast<uint64_t*>(counters);
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(&got);
+    for (size_t k = 0; k < sizeof got / 8; k++) dst[k] += src[k];
+  }
+  return RM_OK;
+}
+
+int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
+                    int tile_first, int tile_stride, float* d_pixels, uint32_t* d_argb) {
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n * 16, c->stream));
+  for (int i = 0; i < iter; i++)
+    HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, d_mc + (size_t)i * RM_TABLE_FLOATS,
+                                    d_opts + i, resx, d_pixels, n, 0, n, tile_first, tile_stride,
+                                    nullptr));
+  if (d_argb) HIP_TRY(rmk::launch_tonemap(c->stream, d_pixels, d_opts, d_argb, n));
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  c->timed = true;
+  c->launches = iter + (d_argb ? 1 : 0);
+  return RM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rm_last_error(void) { return g_err; }
+int rm_abi_version(void) { return 1; }
+
+int rm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int rm_create(int device_id, rm_ctx** out) {
+  if (!out) return fail(RM_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(RM_EDEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(RM_EINVAL, "device_id %d of %d", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RM_EDEVICE, "device %d is %s; this library is built for gfx950 only", device_id,
+                prop.gcnArchName);
+  rm_ctx* c = new (std::nothrow) rm_ctx();
+  if (!c) return fail(RM_EDEVICE, "out of host memory");
+  c->device = device_id;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    rm_destroy(c);
+    return fail(RM_EDEVICE, "stream/event creation: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return RM_OK;
+}
+
+void rm_destroy(rm_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf,
+                    &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
+  for (DevBuf* b : bufs) b->release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int rm_set_stream(rm_ctx* c, void* hip_stream) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return RM_OK;
+}
+
+int rm_synchronize(rm_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+static int check_res(int rx, int ry, int rz) {
+  if (rx <= 0 || ry <= 0 || rz <= 0) return fail(RM_EINVAL, "volume resolution %dx%dx%d", rx, ry, rz);
+  // the kernels index with 32-bit ints like the reference (renderer.cl:167)
+  if ((long long)rx * ry * rz > 0x7fffffffLL)
+    return fail(RM_EINVAL, "volume %dx%dx%d exceeds the 2^31-1 voxel index range", rx, ry, rz);
+  return RM_OK;
+}
+
+int rm_set_volume(rm_ctx* c, const uint8_t* voxels, int rx, int ry, int rz) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!voxels) return fail(RM_EINVAL, "voxels is NULL");
+  rc = check_res(rx, ry, rz);
+  if (rc) return rc;
+  const size_t bytes = (size_t)rx * ry * rz;
+  HIP_TRY(c->vox_buf.reserve(bytes));
+  HIP_TRY(hipMemcpyAsync(c->vox_buf.p, voxels, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
+  c->rx = rx; c->ry = ry; c->rz = rz;
+  return RM_OK;
+}
+
+int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_voxels) return fail(RM_EINVAL, "d_voxels is NULL");
+  rc = check_res(rx, ry, rz);
+  if (rc) return rc;
+  c->d_vox = static_cast<const uint8_t*>(d_voxels);
+  c->rx = rx; c->ry = ry; c->rz = rz;
+  return RM_OK;
+}
+
+int rm_render_image(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n) {
+  return render_pass_host(c, mc, opts544, pixels, n, 0, n, nullptr);
+}
+int rm_render_image_range(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n,
+                          int id0, int id1) {
+  if (id0 < 0 || id1 < id0) return fail(RM_EINVAL, "id range [%d,%d)", id0, id1);
+  return render_pass_host(c, mc, opts544, pixels, n, id0, id1, nullptr);
+}
+int rm_render_image_counted(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n,
+                            rm_counters* out) {
+  if (!out) return fail(RM_EINVAL, "out is NULL");
+  return render_pass_host(c, mc, opts544, pixels, n, 0, n, out);
+}
+
+int rm_tonemap_image(rm_ctx* c, const float* pixels, const void* opts544, uint32_t* argb, int n) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (n < 0) return fail(RM_EINVAL, "n = %d", n);
+  if (!opts544 || ((!pixels || !argb) && n > 0)) return fail(RM_EINVAL, "NULL buffer");
+  if (n == 0) return RM_OK;
+  HIP_TRY(c->opts_buf.reserve(RM_OPTS_BYTES));
+  HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
+  HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
+  HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts544, RM_OPTS_BYTES, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pix_buf.p, pixels, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(rmk::launch_tonemap(c->stream, static_cast<const float*>(c->pix_buf.p),
+                              static_cast<const RmOpts*>(c->opts_buf.p),
+                              static_cast<uint32_t*>(c->argb_buf.p), n));
+  HIP_TRY(hipMemcpyAsync(argb, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
+                    float* pixels_out, uint32_t* argb_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!opts_array || !mc_array) return fail(RM_EINVAL, "NULL buffer");
+  if (iter <= 0) return fail(RM_EINVAL, "iter = %d", iter);
+  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  for (int i = 0; i < iter; i++) {
+    rc = check_opts(c, static_cast<const char*>(opts_array) + (size_t)i * RM_OPTS_BYTES, n);
+    if (rc) return rc;
+  }
+  if (n == 0) return RM_OK;
+  HIP_TRY(c->opts_buf.reserve((size_t)iter * RM_OPTS_BYTES));
+  HIP_TRY(c->mc_buf.reserve((size_t)iter * RM_TABLE_FLOATS * 4));
+  HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
+  if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
+  HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts_array, (size_t)iter * RM_OPTS_BYTES,
+                         hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->mc_buf.p, mc_array, (size_t)iter * RM_TABLE_FLOATS * 4,
+                         hipMemcpyHostToDevice, c->stream));
+  RmOpts o0;
+  memcpy(&o0, opts_array, sizeof o0);
+  rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
+                       static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
+                       static_cast<float*>(c->pix_buf.p),
+                       argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr);
+  if (rc) return rc;
+  if (pixels_out)
+    HIP_TRY(hipMemcpyAsync(pixels_out, c->pix_buf.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+  if (argb_out)
+    HIP_TRY(hipMemcpyAsync(argb_out, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, int n,
+                    int tile_first, int tile_stride, float* d_pixels, uint32_t* d_argb) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_opts || !d_mc || !d_pixels) return fail(RM_EINVAL, "NULL device buffer");
+  if (iter <= 0 || n <= 0) return fail(RM_EINVAL, "iter = %d, n = %d", iter, n);
+  if (tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
+    return fail(RM_EINVAL, "tile partition (%d,%d)", tile_first, tile_stride);
+  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  // resolution.x is needed on the host to size the grid: fetch opts[0] once.
+  RmOpts o0;
+  HIP_TRY(hipMemcpyAsync(&o0, d_opts, sizeof o0, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  rc = check_opts(c, &o0, n);
+  if (rc) return rc;
+  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, o0.resolution[0], iter, n,
+                         tile_first, tile_stride, d_pixels, d_argb);
+}
+
+int rm_last_frame_timing(rm_ctx* c, float* ms, int* launches) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->timed) return fail(RM_ESTATE, "no frame has been rendered");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+  if (ms) *ms = t;
+  if (launches) *launches = c->launches;
+  return RM_OK;
+}
+
+int rm_selftest_prims(rm_ctx* c, int op, const float* a, const float* b, uint32_t* out, int n) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!a || !out || n < 0 || op < 0 || op > 8) return fail(RM_EINVAL, "bad argument");
+  if (n == 0) return RM_OK;
+  const size_t bytes = (size_t)n * 4;
+  HIP_TRY(c->prim_a.reserve(bytes));
+  HIP_TRY(c->prim_o.reserve(bytes));
+  HIP_TRY(hipMemcpyAsync(c->prim_a.p, a, bytes, hipMemcpyHostToDevice, c->stream));
+  if (b) {
+    HIP_TRY(c->prim_b.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(c->prim_b.p, b, bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(rmk::launch_prims(c->stream, op, static_cast<const float*>(c->prim_a.p),
+                            b ? static_cast<const float*>(c->prim_b.p) : nullptr,
+                            static_cast<uint32_t*>(c->prim_o.p), n));
+  HIP_TRY(hipMemcpyAsync(out, c->prim_o.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+// rm_kernels.h -- host-side launchers of the gfx950 kernels (rm_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "rm_opts.h"
+
+namespace rmk {
+struct Counters;
+
+// number of 8x8 tiles covering work-items 0..n-1 of an image `resx` wide
+int tiles_total(int resx, int n);
+
+hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, const float* d_mc,
+                              const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
+                              int id1, int tile_first, int tile_stride, Counters* d_counters);
+hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
+                          uint32_t* d_argb, int n);
+hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,
+                        int n);
+}  // namespace rmk

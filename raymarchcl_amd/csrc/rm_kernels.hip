@@ -1,0 +1,164 @@
+// rm_kernels.hip -- gfx950 kernels of the render path and their launchers.
+//
+//   render_pass_kernel   == one NDRange of the reference's RenderImage
+//                           (renderer.cl:478-494): one lane per sample, the
+//                           accumulator is blended in place.
+//   tonemap_kernel       == TonemapImage (renderer.cl:448-454, 496-508).
+//   prims_kernel         -- device side of rm_selftest_prims.
+//
+// Work decomposition: the image is cut into 8x8-pixel tiles (row-major tile
+// order); one 64-lane wavefront owns one tile so that the rays of a wave are
+// spatially coherent (their voxel fetches share cache lines), four tiles per
+// 256-thread workgroup.  Everything that is uniform across the launch (the
+// 544-byte option record) is read through a uniform pointer, i.e. by scalar
+// loads into SGPRs -- the reference's per-work-item private copy of the record
+// is what costs it 560 B of scratch per lane on this chip.
+#include <hip/hip_runtime.h>
+
+#include "rm_kernels.h"
+#include "rm_shade.hpp"
+
+namespace {
+
+constexpr int kTile = 8;            // tile edge in pixels; 64 px == one wavefront
+constexpr int kWavesPerBlock = 4;
+
+struct TileGeom {
+  int tiles_x, tiles_total;
+};
+__host__ __device__ inline TileGeom tile_geom(int resx, int n) {
+  const int rows = (n + resx - 1) / resx;
+  TileGeom g;
+  g.tiles_x = (resx + kTile - 1) / kTile;
+  g.tiles_total = g.tiles_x * ((rows + kTile - 1) / kTile);
+  return g;
+}
+
+// lane -> work-item id of the pixel it owns, or -1
+__device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tiles_x, int n,
+                                          int id0, int id1) {
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x = tx * kTile + (lane & (kTile - 1));
+  const int y = ty * kTile + (lane >> 3);
+  if (x >= resx) return -1;
+  const long long id = (long long)y * resx + x;
+  if (id >= n || id < id0 || id >= id1) return -1;
+  return (int)id;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
+    const uint8_t* __restrict__ vox, const float4* __restrict__ mc, const RmOpts* __restrict__ opts,
+    float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
+    rmk::Counters* __restrict__ counters) {
+  const int resx = opts->resolution[0];
+  const TileGeom g = tile_geom(resx, n);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long tile = tile_first + slot * tile_stride;
+  if (tile >= g.tiles_total) return;
+  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
+  rmk::Scene sc{vox, mc, opts};
+  rmk::Tracer<COUNT> tr(sc);
+  if (id >= 0) {
+    const rmk::v3 col = tr.shade(id);
+    const float fb = opts->frameBlend;
+    const float4 p = pixels[id];
+    // mix(p, col, frameBlend): renderer.cl:492
+    pixels[id] = make_float4(p.x + (col.x - p.x) * fb, p.y + (col.y - p.y) * fb,
+                             p.z + (col.z - p.z) * fb, 1.0f);
+  }
+  if (COUNT) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(counters);
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&tr.cnt);
+    for (int k = 0; k < (int)(sizeof(rmk::Counters) / 8); k++) {
+      unsigned long long v = src[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0 && v) atomicAdd(dst + k, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ pixels,
+                                                      const RmOpts* __restrict__ opts,
+                                                      uint32_t* __restrict__ argb, int n) {
+  const float g = opts->gamma;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n;
+       id += (long long)gridDim.x * blockDim.x) {
+    const float4 p = pixels[id];
+    const float c[3] = {p.x, p.y, p.z};
+    uint32_t ch[3];
+    for (int k = 0; k < 3; k++) {
+      const float t = c[k] / (g + c[k]);
+      const float v = t * t * 255.0f;
+      ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
+    }
+    argb[id] = 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
+  }
+}
+
+__global__ void prims_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                             uint32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i];
+  const float y = b ? b[i] : 0.0f;
+  uint32_t r = 0;
+  switch (op) {
+    case 0: r = __float_as_uint(x / y); break;
+    case 1: r = __float_as_uint(rmd::sqrt_rn(x)); break;
+    case 2: r = __float_as_uint(rmd::exp_det(x)); break;
+    case 3: r = __float_as_uint(rmd::exp2_det(x)); break;
+    case 4: r = __float_as_uint(rmd::pow_det(x, y)); break;
+    case 5: r = (uint32_t)rmd::f2i(x); break;
+    case 6: r = rmd::f2u(x); break;
+    case 7: r = (uint32_t)rmd::convert_int_sat(x); break;
+    case 8: r = __float_as_uint(x * y + x); break;
+    default: break;
+  }
+  out[i] = r;
+}
+
+}  // namespace
+
+namespace rmk {
+
+int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
+
+hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, const float* mc,
+                              const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
+                              int id1, int tile_first, int tile_stride, Counters* d_counters) {
+  const TileGeom g = tile_geom(resx, n);
+  if (tile_stride < 1) tile_stride = 1;
+  const long long my_tiles =
+      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
+  if (my_tiles == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((my_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (d_counters)
+    render_pass_kernel<true><<<blocks, 64 * kWavesPerBlock, 0, st>>>(
+        vox, reinterpret_cast<const float4*>(mc), d_opts, reinterpret_cast<float4*>(pixels), n, id0,
+        id1, tile_first, tile_stride, d_counters);
+  else
+    render_pass_kernel<false><<<blocks, 64 * kWavesPerBlock, 0, st>>>(
+        vox, reinterpret_cast<const float4*>(mc), d_opts, reinterpret_cast<float4*>(pixels), n, id0,
+        id1, tile_first, tile_stride, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_tonemap(hipStream_t st, const float* pixels, const RmOpts* d_opts, uint32_t* argb,
+                          int n) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  tonemap_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,
+                        int n) {
+  if (n <= 0) return hipSuccess;
+  prims_kernel<<<(n + 255) / 256, 256, 0, st>>>(op, a, b, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace rmk

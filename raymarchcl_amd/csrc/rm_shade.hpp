@@ -1,0 +1,381 @@
+// rm_shade.hpp -- per-sample ray march + shading for gfx950, written from the
+// behaviour of the reference device functions
+// (/root/reference/resources/renderer.cl:142-476; the function each routine
+// replaces is cited next to it).  Scalar float32 throughout, every expression
+// in the reference's evaluation order, no FMA contraction (see rm_detmath.hpp).
+//
+// This header holds the "straight" formulation: one lane owns one sample from
+// camera ray to final colour.  rm_kernels.hip wraps it in the RenderImage-
+// equivalent kernel; the wave-scheduled variant lives in rm_wave.hpp and is
+// checked against this one.
+#pragma once
+#include "rm_detmath.hpp"
+#include "rm_opts.h"
+
+namespace rmk {
+
+struct v3 { float x, y, z; };
+RM_DEV v3 V(float x, float y, float z) { return v3{x, y, z}; }
+RM_DEV v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+RM_DEV v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+RM_DEV v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+RM_DEV v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+RM_DEV v3 operator-(v3 a) { return V(-a.x, -a.y, -a.z); }
+RM_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RM_DEV v3 cross(v3 a, v3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// a*s + c, two roundings per component (the reference's mad() on a CPU device)
+RM_DEV v3 mads(v3 a, float s, v3 c) { return V(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z); }
+RM_DEV v3 madv(v3 a, v3 b, v3 c) { return V(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z); }
+RM_DEV v3 mixs(v3 a, v3 b, float t) {
+  return V(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t);
+}
+RM_DEV v3 normalize(v3 v) {
+  if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
+  const float s = 1.0f / rmd::sqrt_rn(dot(v, v));
+  return v * s;
+}
+RM_DEV float length(v3 v) { return rmd::sqrt_rn(dot(v, v)); }
+RM_DEV v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+
+// Optional device-side event counters (algorithmic bytes for the roofline).
+struct Counters {
+  unsigned long long vox_reads, mc_reads, rays, dts_calls, march_steps, ao_calls, primary_hits,
+      oob_material;
+};
+
+struct Material { v3 albedo; float r0, smoothness; };
+
+// Everything a sample needs that is uniform across the launch.
+struct Scene {
+  const uint8_t* __restrict__ vox;
+  const float4* __restrict__ mc;
+  const RmOpts* __restrict__ o;
+};
+
+template <bool COUNT>
+struct Tracer {
+  const Scene& sc;
+  Counters cnt;  // per-lane, only touched when COUNT
+  RM_DEV explicit Tracer(const Scene& s) : sc(s), cnt{} {}
+
+  // scatter table lookup: renderer.cl:142-144
+  RM_DEV float4 table(uint32_t seed) {
+    if (COUNT) cnt.mc_reads++;
+    return sc.mc[seed & (RM_TABLE_ENTRIES - 1)];
+  }
+
+  // materials[id] by byte offset, defined for every id (see oracle/rm_restate.c)
+  RM_DEV Material material(int id) {
+    Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
+    const int off = (int)offsetof(RmOpts, materials) + (int)sizeof(RmMaterial) * id;
+    if (id < -13 || id > 3) {
+      if (COUNT) cnt.oob_material++;
+      return m;
+    }
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sc.o) + off);
+    m.albedo = V(p[0], p[1], p[2]);
+    m.r0 = p[4];
+    m.smoothness = p[5];
+    return m;
+  }
+
+  // slab test: renderer.cl:153-161
+  RM_DEV float box_entry(v3 p, v3 d) {
+    const RmOpts& o = *sc.o;
+    const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
+                loz = (o.voxelBoundsMin[2] - p.z) / d.z;
+    const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
+                hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
+    const float nx = rmd::fmin_cl(hix, lox), ny = rmd::fmin_cl(hiy, loy), nz = rmd::fmin_cl(hiz, loz);
+    const float a = rmd::fmax_cl(rmd::fmax_cl(nx, 0.0f), rmd::fmax_cl(ny, nz));
+    const float fx = rmd::fmax_cl(hix, lox), fy = rmd::fmax_cl(hiy, loy), fz = rmd::fmax_cl(hiz, loz);
+    const float b = rmd::fmin_cl(fx, rmd::fmin_cl(fy, fz));
+    return b > a ? a : -1.0f;
+  }
+
+  RM_DEV bool in_grid(int qx, int qy, int qz) {
+    const RmOpts& o = *sc.o;
+    return qz >= 0 && qz < o.voxelRes[2] && qy >= 0 && qy < o.voxelRes[1] && qx >= 0 &&
+           qx < o.voxelRes[0];
+  }
+  // binary occupancy: renderer.cl:172-178
+  RM_DEV float solid(int qx, int qy, int qz) {
+    const RmOpts& o = *sc.o;
+    if (!in_grid(qx, qy, qz)) return 0.0f;
+    if (COUNT) cnt.vox_reads++;
+    return rmd::step_cl((float)o.isoVal, (float)sc.vox[qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx]);
+  }
+  // negated central difference: renderer.cl:180-188
+  RM_DEV v3 cell_gradient(int qx, int qy, int qz) {
+    const float gx = solid(qx + 1, qy, qz) - solid(qx - 1, qy, qz);
+    const float gy = solid(qx, qy + 1, qz) - solid(qx, qy - 1, qz);
+    const float gz = solid(qx, qy, qz + 1) - solid(qx, qy, qz - 1);
+    return V(-gx, -gy, -gz);
+  }
+  // 3x3x3 sum of gradients of solid cells: renderer.cl:190-203
+  RM_DEV v3 smooth_gradient(int qx, int qy, int qz) {
+    v3 n = V(0.f, 0.f, 0.f);
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++)
+          if (solid(qx + dx, qy + dy, qz + dz) > 0.0f)
+            n = n + cell_gradient(qx + dx, qy + dy, qz + dz);
+    return normalize(n);
+  }
+
+  // distance estimate: renderer.cl:209-237
+  RM_DEV void scene_distance(v3 rpos, v3 dir, int steps, bool smooth, float& dist, float& code,
+                             v3& nrm) {
+    const RmOpts& o = *sc.o;
+    if (COUNT) cnt.dts_calls++;
+    const float h = rpos.y + o.groundY;
+    float rd, rc;
+    if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
+    nrm = (rd < 1e5f) ? V(0.f, 1.f, 0.f) : -dir;
+    const float t_in = box_entry(rpos, dir);
+    if (t_in >= 0.0f && t_in < rd) {
+      const float sf = (float)steps * 0.5f;
+      const v3 ivs = ld3(o.invVoxelScale);
+      const v3 delta = V(dir.x / sf, dir.y / sf, dir.z / sf) * ivs;
+      v3 p = rpos + ld3(o.voxelBounds);
+      if (t_in > 0.0f) p = mads(dir, t_in, p);
+      p = p * ivs;
+      const float frx = (float)o.voxelRes[0], fry = (float)o.voxelRes[1], frz = (float)o.voxelRes[2];
+      const int iso = o.isoVal;
+      while (--steps >= 0) {
+        const int qx = rmd::convert_int_sat(p.x * frx);
+        const int qy = rmd::convert_int_sat(p.y * fry);
+        const int qz = rmd::convert_int_sat(p.z * frz);
+        if (COUNT) cnt.march_steps++;
+        if (!in_grid(qx, qy, qz)) break;
+        if (COUNT) cnt.vox_reads++;
+        const int v = sc.vox[qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx];
+        if (v > iso) {
+          nrm = smooth ? smooth_gradient(qx, qy, qz) : normalize(cell_gradient(qx, qy, qz));
+          const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
+          const float d = length(rpos - hit) - o.voxelSize;
+          if (d < rd) { rd = d; rc = v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }
+          break;
+        }
+        p = p + delta;
+      }
+    }
+    dist = rd;
+    code = rc;
+  }
+
+  struct Hit { v3 pos, normal; float distance; int objectID; };
+
+  // outer march: renderer.cl:239-257
+  RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
+    const RmOpts& o = *sc.o;
+    if (COUNT) cnt.rays++;
+    r.distance = o.startDist;
+    while (--maxSteps >= 0) {
+      r.pos = mads(rdir, r.distance, ro);
+      float sd, scode;
+      scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd, scode, r.normal);
+      r.objectID = rmd::f2i(scode);
+      if (__builtin_fabsf(sd) <= o.eps || r.distance >= maxDist) break;
+      r.distance += sd;
+    }
+    if (r.distance >= maxDist) {
+      r.pos = mads(rdir, r.distance, ro);
+      r.objectID = -1;
+      r.distance = 1000.0f;
+    }
+  }
+
+  // renderer.cl:259-261
+  RM_DEV v3 sky(v3 dir) {
+    const RmOpts& o = *sc.o;
+    return mixs(ld3(o.skyColor1), ld3(o.skyColor2), dir.y * 0.5f + 0.5f);
+  }
+
+  struct Sample { v3 eye; v3 mcNormal; float px, py; float time; };
+
+  // jittered light position: renderer.cl:263-269
+  RM_DEV v3 light_at(const Sample& s, int i) {
+    const RmOpts& o = *sc.o;
+    const uint32_t seed = rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
+    const float4 r = table(seed);
+    return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
+  }
+  // renderer.cl:271-273
+  RM_DEV v3 reflect(v3 v, v3 n) {
+    const float k = 2.0f * dot(v, n);
+    return v - n * k;
+  }
+  // fog + flares: renderer.cl:275-290
+  RM_DEV v3 atmosphere(const Sample& s, v3 ro, v3 rdir, float dist, v3 col) {
+    const RmOpts& o = *sc.o;
+    const float fa = 1.0f - rmd::exp_det(dist * dist * -o.fogPow);
+    const v3 sk = sky(rdir);
+    col = V((sk.x - col.x) * fa + col.x, (sk.y - col.y) * fa + col.y, (sk.z - col.z) * fa + col.z);
+    const int nl = o.numLights;
+    for (int i = 0; i < nl; i++) {
+      v3 lp = light_at(s, i);
+      const float d = rmd::clamp_cl(dot(lp - ro, rdir), 0.0f, dist);
+      lp = mads(rdir, d, ro - lp);
+      const float k = o.flareAmp / dot(lp, lp);
+      col = mads(ld3(o.lightColor[i]), k, col);
+    }
+    return col;
+  }
+  // renderer.cl:292-301
+  RM_DEV float shadow_term(v3 p, v3 ldir, float lmax) {
+    Hit h{};
+    march(p, ldir, h, lmax, sc.o->shadowIter, false);
+    return rmd::step_cl(lmax, h.distance);
+  }
+  // renderer.cl:304-311
+  RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) {
+    const float d = rmd::clamp_cl(1.0f - dot(n, -view), 0.0f, 1.0f);
+    if (d > 0.0f) {
+      const float d2 = d * d;
+      return (1.0f - r0) * (smooth * d2 * d2 * d) + r0;
+    }
+    return 0.0f;
+  }
+  // renderer.cl:317-325
+  RM_DEV float blinn_phong(float smooth, v3 raydir, v3 ldir, v3 n) {
+    const float nh = dot(normalize(ldir - raydir), n);
+    if (nh > 0.0f) {
+      const float sp = rmd::exp2_det(6.0f * smooth + 4.0f);
+      return rmd::pow_det(nh, sp) * (sp + 2.0f) * 0.125f;
+    }
+    return 0.0f;
+  }
+  // renderer.cl:327-346
+  RM_DEV float occlusion(const Sample& s, v3 pos, v3 normal) {
+    const RmOpts& o = *sc.o;
+    if (COUNT) cnt.ao_calls++;
+    float ao = 1.0f;
+    float d = 0.0f;
+    uint32_t seed =
+        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+    for (int i = 0; i <= o.aoIter && (double)ao > 0.01; i++) {
+      d += o.aoStepDist;
+      seed += 37u;
+      const float4 r = table(seed);
+      const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, normal));
+      float sd, scode;
+      v3 nn;
+      scene_distance(mads(n, d, pos), n, o.maxVoxelIter / 2, false, sd, scode, nn);
+      ao *= 1.0f - rmd::fmax_cl((d - sd) * o.aoAmp / d, 0.0f);
+    }
+    return ao;
+  }
+  // renderer.cl:348-381
+  RM_DEV v3 lighting(const Sample& s, v3 raydir, v3 hitpos, const Material& m, v3 normal,
+                     v3 reflectCol) {
+    const RmOpts& o = *sc.o;
+    const float ao = occlusion(s, hitpos, normal);
+    v3 diff = sky(normal) * ao;
+    v3 spec = reflectCol * ao;
+    v3 out = V(0.f, 0.f, 0.f);
+    const int nl = o.numLights;
+    for (int i = 0; i < nl; i++) {
+      const v3 dl = light_at(s, i) - hitpos;
+      const float d2 = dot(dl, dl);
+      const float att = 1.0f / d2;
+      if (att > o.minLightAtt) {
+        const v3 ldir = normalize(dl);
+        const float sh = shadow_term(mads(ldir, o.shadowBias, hitpos), ldir,
+                                     rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist));
+        if (sh > 0.0f) {
+          const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
+          diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+          spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+        }
+      }
+      diff = diff * m.albedo;
+      out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
+    }
+    const float fl = (float)nl;
+    return V(out.x / fl, out.y / fl, out.z / fl);
+  }
+  // one reflection bounce: renderer.cl:383-405
+  RM_DEV v3 bounce_colour(const Sample& s, v3 ro, v3 rdir, Hit& h) {
+    const RmOpts& o = *sc.o;
+    march(ro, rdir, h, o.maxDist, o.maxIter, false);
+    v3 col;
+    if (h.objectID < 0) {
+      col = sky(rdir);
+    } else {
+      const Material m = material(h.objectID);
+      col = lighting(s, rdir, h.pos, m, h.normal, sky(reflect(rdir, h.normal)));
+    }
+    return atmosphere(s, ro, rdir, h.distance, col);
+  }
+  // primary shading: renderer.cl:407-446
+  RM_DEV v3 sample_colour(const Sample& s, v3 ro, v3 rdir) {
+    const RmOpts& o = *sc.o;
+    Hit h{};
+    march(ro, rdir, h, o.maxDist, o.maxIter, true);
+    v3 col;
+    if (h.distance >= o.maxDist) {
+      col = sky(rdir);
+    } else {
+      if (COUNT) cnt.primary_hits++;
+      const Material m = material(h.objectID);
+      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      const v3 norm = mads(s.mcNormal, k, h.normal);
+      v3 refl = V(0.f, 0.f, 0.f);
+      if (m.r0 > 0.0f && o.reflectIter > 0) {
+        Hit rh{};
+        rh.pos = h.pos;
+        rh.normal = norm;
+        v3 dir = rdir;
+        for (int i = 0; i < o.reflectIter; i++) {
+          dir = reflect(dir, rh.normal);
+          const v3 from = mads(dir, 0.0075f, rh.pos);
+          refl = refl + bounce_colour(s, from, dir, rh);
+          if (rh.objectID < 0) break;
+          if ((double)material(rh.objectID).r0 < 0.001) break;
+        }
+      } else {
+        refl = sky(reflect(rdir, norm));
+      }
+      col = lighting(s, rdir, h.pos, m, norm, refl);
+    }
+    return atmosphere(s, ro, rdir, h.distance, col);
+  }
+
+  // renderer.cl:467-476 (sample state) and :456-465 (camera ray)
+  RM_DEV Sample sample_init(int id) {
+    const RmOpts& o = *sc.o;
+    Sample s;
+    s.time = o.time;
+    const int resx = o.resolution[0];
+    const float fx = (float)(id % resx), fy = (float)(id / resx);
+    const float4 mcPos = table((uint32_t)id * 17u + rmd::f2u(o.time * 3141.3862f));
+    const float4 t = table((uint32_t)id * 37u + rmd::f2u(o.time * 1859.1467f));
+    s.mcNormal = normalize(V(t.x, t.y, t.z));
+    s.px = fx + mcPos.z;
+    s.py = fy + mcPos.w;
+    s.eye = mads(V(s.mcNormal.z, s.mcNormal.x, s.mcNormal.y), o.dof, ld3(o.eyePos));
+    return s;
+  }
+  RM_DEV v3 camera_dir(const Sample& s) {
+    const RmOpts& o = *sc.o;
+    const v3 fwd = normalize(ld3(o.targetPos) - s.eye);
+    const v3 right = normalize(cross(fwd, ld3(o.up)));
+    float vx = s.px / (float)o.resolution[0] * o.fov - o.fov * 0.5f;
+    float vy = s.py / (float)o.resolution[1] * o.fov - o.fov * 0.5f;
+    vy *= -o.invAspect;
+    const v3 upv = cross(right, fwd);
+    return normalize(right * vx + upv * vy + fwd);
+  }
+
+  // colour * exposure of work-item `id` (the value RenderImage blends in, renderer.cl:491)
+  RM_DEV v3 shade(int id) {
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    return sample_colour(s, s.eye, rdir) * sc.o->exposure;
+  }
+};
+
+}  // namespace rmk

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+REFERENCE_PRESENT = os.path.exists("/root/reference/resources/renderer.cl")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    skip_ref = pytest.mark.skip(reason="/root/reference is not present on this machine")
+    for item in items:
+        if "reference" in item.keywords and not REFERENCE_PRESENT:
+            item.add_marker(skip_ref)
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    """The CPU restatement (test infrastructure), built on demand."""
+    import oracle
+
+    oracle.build(ref=REFERENCE_PRESENT)
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def native():
+    """The product library; built on demand (hipcc cross-compiles without a GPU)."""
+    from raymarchcl_amd import _native
+
+    _native.build()
+    return _native
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(native):
+    ctx = native.Context(0)  # raises loudly when there is no gfx950 device
+    yield ctx
+    ctx.close()
+
+
+def load_golden(name):
+    import numpy as np
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    return {k: z[k] for k in z.files}

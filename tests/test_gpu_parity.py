@@ -1,0 +1,148 @@
+"""Parity of the HIP path (through the C ABI) with the oracle: the golden
+fixtures generated from the reference kernel, the CPU restatement on the same
+seeded inputs, and size-independent properties at BASELINE's full sizes.
+Bit-exact: the path is float32 with a pinned IEEE op sequence."""
+import numpy as np
+import pytest
+
+import scenes
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+NAMES = list(scenes.SCENES)
+
+
+def _eq(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_frame_matches_reference_fixture(gpu_ctx, name):
+    g = load_golden(name)
+    sc = scenes.build(name)
+    gpu_ctx.set_volume(g["vox"], tuple(int(v) for v in g["vres"]))
+    px, argb = gpu_ctx.render_frame(g["opts"].tobytes(), sc["mc"], int(g["n"]))
+    assert _eq(px, g["pixels"]), f"{(px.view(np.uint32) != g['pixels'].view(np.uint32)).sum()} floats differ"
+    assert np.array_equal(argb, g["argb"])
+
+
+@pytest.mark.parametrize("name", ["c1_orange", "metal_3spp", "ragged_50x37"])
+def test_single_pass_entry_points_match_oracle(gpu_ctx, oracle_mod, native, name):
+    """rm_render_image / _range / _counted + rm_tonemap_image == RenderImage / TonemapImage."""
+    sc = scenes.build(name)
+    n = sc["n"]
+    gpu_ctx.set_volume(sc["vox"], sc["vres"])
+    rng = np.random.default_rng(1)
+    start = rng.uniform(0, 4, 4 * n).astype(np.float32)  # a non-zero accumulator to blend into
+    mc = sc["mc"][0].copy()
+    o = sc["opts"][:544]
+    st = oracle_mod.Stats()
+    want = oracle_mod.render_image(sc["vox"], mc, o, start.copy(), n=n, stats=st)
+    cnt = native.Counters()
+    got = gpu_ctx.render_image(mc, o, start.copy(), n=n, counters=cnt)
+    assert _eq(got, want)
+    assert cnt.as_dict() == st.as_dict()  # same algorithmic work, event for event
+    # sub-ranges (what a tile of the NDRange does)
+    a, b = n // 3, n // 3 + 777
+    want_r = oracle_mod.render_image(sc["vox"], mc, o, start.copy(), n=n, id0=a, id1=b)
+    got_r = gpu_ctx.render_image(mc, o, start.copy(), n=n, id0=a, id1=b)
+    assert _eq(got_r, want_r)
+    assert np.array_equal(gpu_ctx.tonemap_image(want, o, n=n), oracle_mod.tonemap_image(want, o, n=n))
+
+
+def test_tonemap_edge_values(gpu_ctx, oracle_mod):
+    px = np.zeros((8, 4), np.float32)
+    px[:, 0] = [0, 1e-9, 0.5, 1.5, 1e9, np.inf, -0.2, np.nan]
+    px[:, 1] = [3.0, 100.0, -1.5, -3.0, 1e-3, 7.0, 0.25, 1.0]
+    px[:, 2] = px[::-1, 0]
+    o = scenes.build("c1_orange")["opts"][:544]
+    assert np.array_equal(gpu_ctx.tonemap_image(px.reshape(-1).copy(), o),
+                          oracle_mod.tonemap_image(px.reshape(-1).copy(), o))
+
+
+def test_config1_full_frame(gpu_ctx, oracle_mod):
+    """BASELINE config 1 at full size vs the reference's hashes."""
+    g = load_golden("c1_full")
+    sc = scenes.build(dict(scenes.SCENES["c1_orange"], w=256, h=256))
+    gpu_ctx.set_volume(sc["vox"], sc["vres"])
+    px, argb = gpu_ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+    want, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    assert _eq(px, want) and np.array_equal(argb, want_argb)  # incl. the undefined work-item
+    und = g["undefined_ids"]
+    px.reshape(-1, 4)[und] = 0
+    argb[und] = 0
+    assert scenes.sha(px) == str(g["pixels_sha"]) and scenes.sha(argb) == str(g["argb_sha"])
+
+
+def test_error_paths(gpu_ctx, native):
+    sc = scenes.build("c1_orange")
+    ctx = native.Context(0)
+    px = np.zeros(4 * sc["n"], np.float32)
+    with pytest.raises(native.RmError):  # no volume yet
+        ctx.render_image(sc["mc"][0].copy(), sc["opts"][:544], px)
+    ctx.set_volume(sc["vox"], sc["vres"])
+    bad = bytearray(sc["opts"][:544])
+    bad[160:164] = np.int32(32).tobytes()  # voxelRes.x disagrees with the volume
+    with pytest.raises(native.RmError):
+        ctx.render_image(sc["mc"][0].copy(), bytes(bad), px)
+    with pytest.raises(ValueError):
+        ctx.set_volume(sc["vox"][:100], sc["vres"])
+    ctx.close()
+
+
+# ---- BASELINE config 2 size: 256^3 gyroid, 1280x720 (properties + sampled oracle) ----
+
+@pytest.fixture(scope="module")
+def config2():
+    spec = dict(vol="gyroid", vres=256, w=1280, h=720, iter=2, mat="orange-stripes", theta=-45,
+                dist=2.25, dof=0.025)
+    return scenes.build(spec)
+
+
+def test_config2_sampled_against_oracle_and_partition_invariance(gpu_ctx, oracle_mod, config2):
+    import torch
+
+    sc = config2
+    n, it = sc["n"], sc["iter"]
+    gpu_ctx.set_volume(sc["vox"], sc["vres"])
+    px, argb = gpu_ctx.render_frame(sc["opts"], sc["mc"], n)
+    assert not np.isnan(px).any() and (px.reshape(-1, 4)[:, 3] == 1.0).all()
+    # determinism: a second run is bit-identical
+    px2, _ = gpu_ctx.render_frame(sc["opts"], sc["mc"], n, want_argb=False)
+    assert _eq(px, px2)
+    # oracle on 3000 random work-items + 2 full rows, all passes in order
+    rng = np.random.default_rng(0)
+    ids = np.unique(np.concatenate([rng.integers(0, n, 3000), np.arange(1280 * 300, 1280 * 301),
+                                    np.arange(1280 * 500, 1280 * 501), [0, n - 1]]))
+    want = np.zeros(4 * n, np.float32)
+    for i in range(it):
+        for lo, hi in _runs(ids):
+            oracle_mod.render_image(sc["vox"], sc["mc"][i].copy(), sc["opts"][i * 544:(i + 1) * 544],
+                                    want, n=n, id0=lo, id1=hi, threads=1)
+    assert _eq(px.reshape(-1, 4)[ids], want.reshape(-1, 4)[ids])
+    assert np.array_equal(argb[ids], oracle_mod.tonemap_image(want, sc["opts"][:544], n=n)[ids])
+    # tile partition (the multi-GPU split): union of 3 interleaved partitions == full frame
+    dev = torch.device("cuda:0")
+    d_opts = torch.frombuffer(bytearray(sc["opts"]), dtype=torch.uint8).to(dev)
+    d_mc = torch.from_numpy(sc["mc"]).to(dev)
+    acc = np.zeros(4 * n, np.float32)
+    for r in range(3):
+        d_px = torch.empty(4 * n, dtype=torch.float32, device=dev)
+        gpu_ctx.frame_device(d_opts.data_ptr(), d_mc.data_ptr(), it, n, d_px.data_ptr(), None, r, 3)
+        gpu_ctx.synchronize()
+        part = d_px.cpu().numpy()
+        assert not (np.logical_and(part != 0, acc != 0)).any()  # partitions are disjoint
+        acc += part
+    assert _eq(acc, px)
+
+
+def _runs(ids):
+    lo = prev = int(ids[0])
+    for v in ids[1:]:
+        v = int(v)
+        if v != prev + 1:
+            yield lo, prev + 1
+            lo = v
+        prev = v
+    yield lo, prev + 1
