@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline workload on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of BASELINE.json configs[1]: the 256^3 gyroid byte
+volume (generators.clj:27-42), 1280x720, 16 passes (spp) with DOF 0.025,
+preset :orange-stripes, camera of the README example -- i.e. the whole
+pipeline of core.clj:76-97 (zeroed accumulator, 16 RenderImage passes in
+order, TonemapImage) with every input already resident in HBM.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles
+are interleaved over the ranks and the tile accumulators are gathered on rank
+0 over RCCL -- the total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.  `value` = primary rays (= samples) per second
+of the whole job; `roofline` prices the dominant kernel (one RenderImage pass)
+against HBM bandwidth using the ALGORITHMIC bytes of that pass;
+`cpu_baseline` is the CPU restatement of the reference kernel (oracle/) timed
+on this box's host cores on a bounded sample -- reported, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: volume, vres, width, height, spp, render-option extras
+    "c2": dict(desc="256^3 gyroid, 1280x720, 16 spp + DOF 0.025, :orange-stripes", vol="gyroid",
+               vres=256, w=1280, h=720, spp=16, mat="orange-stripes", dof=0.025),
+    "c1": dict(desc="64^3 gyroid, 256x256, 1 spp, :orange-stripes", vol="gyroid", vres=64, w=256,
+               h=256, spp=1, mat="orange-stripes"),
+    "c3": dict(desc="512^3 procedural blob volume (bunny stand-in), 1920x1080, 16 spp, :metal",
+               vol="blobs", vres=512, w=1920, h=1080, spp=16, mat="metal"),
+    "c4": dict(desc="256^3 gyroid, 3840x2160, 64 spp + DOF 0.025, :orange-stripes", vol="gyroid",
+               vres=256, w=3840, h=2160, spp=64, mat="orange-stripes", dof=0.025),
+}
+
+
+def build_inputs(wl):
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen
+    from raymarchcl_amd import structs
+
+    vres = wl["vres"]
+    vox = gen.make_gyroid_volume(vres) if wl["vol"] == "gyroid" else gen.make_blob_volume(vres)
+    extra = {k: wl[k] for k in ("dof",) if k in wl}
+    opts = b"".join(
+        structs.encode_bytes(rm.render_options(
+            width=wl["w"], height=wl["h"], vres=[vres] * 3, t=i * 0.333, iter=wl["spp"],
+            eyepos=rm.compute_eyepos(-45, 2.25, 0.35), targetpos=[0, -0.4, 0], mat=wl["mat"], **extra))
+        for i in range(wl["spp"]))
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=1000 + i) for i in range(wl["spp"])])
+    return vox, (vres,) * 3, opts, mc
+
+
+def load_traffic(path):
+    """HBM bytes per render-pass launch from a committed rocprofv3 --pmc
+    summary (profiles/*.json written by tools/pmc_summary.py), or None."""
+    if path and os.path.exists(path):
+        try:
+            return json.load(open(path)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=2, help="passes of the workload the CPU baseline renders")
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from raymarchcl_amd import _native, multigpu
+
+    _native.build()
+    wl = WORKLOADS[args.workload]
+    vox, vres, opts, mc = build_inputs(wl)
+    n, width, spp = wl["w"] * wl["h"], wl["w"], wl["spp"]
+    fr = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev,
+                                want_pixels=True, want_argb=True)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        fr.render()
+    sync_all()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fr.render()
+        if rank == 0 and world == 1:
+            pass
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # Dominant kernel: the RenderImage pass.  HIP events bracket the `spp` pass
+    # launches of a frame on the stream they run on; measured on extra frames
+    # right after the timed region so the event reads do not perturb it.
+    for _ in range(5):
+        fr.render()
+        ms, launches = fr.ctx.last_frame_timing()
+        kernel_ms.append(ms / launches)
+    pass_ms = float(np.median(kernel_ms))
+
+    out = None
+    if rank == 0:
+        samples_per_frame = n * spp
+        value = samples_per_frame * args.steps / elapsed / 1e6
+        # algorithmic bytes of the workload: exact event counts from the counting
+        # variant of the kernel (same algorithm, +counters), untimed, all passes
+        cnt = _native.Counters()
+        cctx = _native.Context(local_rank)
+        cctx.set_volume(vox, vres)
+        scratch = np.zeros(4 * n, dtype=np.float32)
+        for i in range(spp):
+            cctx.render_image(np.ascontiguousarray(mc[i]), opts[i * 544:(i + 1) * 544], scratch, n=n,
+                              counters=cnt)
+        cctx.close()
+        c = cnt.as_dict()
+        alg_bytes_frame = c["vox_reads"] * 1 + c["mc_reads"] * 16 + samples_per_frame * 32
+        alg_bytes_pass = alg_bytes_frame / spp  # one launch = one pass over this rank's tiles
+        alg_bytes_launch = alg_bytes_pass / world
+        achieved = alg_bytes_launch / (pass_ms * 1e-3) / 1e9
+        traffic = load_traffic(args.traffic) if (world == 1 and args.workload == "c2") else None
+        out = {
+            "metric": "Mrays/s (primary rays = pixel samples per second) + ms/frame, 256^3 gyroid 1280x720x16spp",
+            "value": round(value, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]],
+                       "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+            "all_rays_per_s_M": round((c["rays"] + c["ao_calls"]) * args.steps / elapsed / 1e6, 2),
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "render_pass_kernel", "kernel_ms": round(pass_ms, 4),
+                "alg_bytes_per_launch": int(alg_bytes_launch),
+                "alg_bytes_per_sample": round(alg_bytes_frame / samples_per_frame, 1),
+                "vox_reads_per_sample": round(c["vox_reads"] / samples_per_frame, 1),
+                "table_reads_per_sample": round(c["mc_reads"] / samples_per_frame, 2),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vox, opts, mc, n, spp, args.cpu_passes)
+    fr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(vox, opts, mc, n, spp, passes):
+    """CPU restatement of the reference kernel (oracle/rm_restate.c, proved
+    bit-identical to the compiled reference kernel in the build container) on
+    all host threads; bounded sample = the first `passes` passes of the frame."""
+    import oracle
+
+    oracle.build(ref=False)
+    cores = int(oracle.restate_lib().rmo_hw_threads())
+    passes = max(1, min(passes, spp))
+    px = np.zeros(4 * n, dtype=np.float32)
+    t0 = time.perf_counter()
+    for i in range(passes):
+        oracle.render_image(vox, np.ascontiguousarray(mc[i]), opts[i * 544:(i + 1) * 544], px, n=n,
+                            threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * passes / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"passes 0..{passes - 1} of {spp}, all {n} pixels each ({dt:.1f} s wall)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -97,17 +97,37 @@ int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, 
                     float* pixels_out, uint32_t* argb_out);
 
 /* ---- device-resident form of the same pipeline (inputs already in HBM) ----
- * d_opts: iter*544 bytes, d_mc: iter tables, d_pixels: n float4 (out),
- * d_argb: n uint32 (out, nullable).  Asynchronous on the context's stream.
- * Only the image tiles t (8x8 pixels, row-major tile order) with
- * t % tile_stride == tile_first are rendered and written -- (0,1) renders
- * everything; (rank, world) is the multi-GPU partition. */
+ * The image is cut into 8x8-pixel tiles, numbered row-major; partition
+ * (tile_first, tile_stride) owns tiles tile_first, tile_first+tile_stride, ...
+ * -- (0,1) is the whole image, (rank, world) the multi-GPU split.  A
+ * partition's accumulators are kept TILE-MAJOR: rm_tiles_per_part() tiles of
+ * 64 float4 each, local tile j at d_tiles[j*64 .. j*64+63] (lane = (y&7)*8 +
+ * (x&7)); this is the buffer ranks exchange.
+ *
+ * rm_frame_device: zero the partition's accumulators, then `iter` RenderImage
+ * passes in order with (opts_i, mc_i) over the partition's tiles.
+ * d_opts: iter*544 bytes, d_mc: iter tables, width: image width in pixels.
+ * Asynchronous on the context's stream. */
+int rm_tiles_per_part(int resx, int n, int parts);
 int rm_frame_device(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
-                    int tile_first, int tile_stride, float* d_pixels, uint32_t* d_argb);
+                    int width, int tile_first, int tile_stride, float* d_tiles);
+/* Un-permute `parts` partitions' accumulators (d_tiles_all = partition 0's
+ * buffer, then partition 1's, ... each rm_tiles_per_part()*64 float4) into the
+ * row-major float4 image d_pixels (nullable) and run TonemapImage with
+ * d_opts[0] into d_argb (nullable).  Asynchronous on the context's stream. */
+int rm_resolve_device(rm_ctx* ctx, const float* d_tiles_all, int parts, const void* d_opts,
+                      int n, int width, float* d_pixels, uint32_t* d_argb);
+/* The device-resident calls take the image width from the caller and do not
+ * read the records back (no host<->device traffic per frame); `width` must be
+ * TRenderOpts.resolution.x.  This synchronous helper fetches the `iter` records
+ * once and applies the same validation the host-buffer entry points do
+ * (resolution, voxelRes against the resident volume, numLights). */
+int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int width);
 
-/* Elapsed milliseconds of the render kernels of the last rm_frame_device /
- * rm_render_frame call, measured with HIP events on the stream they ran on
- * (synchronises).  launches = number of kernel launches in that interval. */
+/* Elapsed milliseconds of the RenderImage-pass kernels of the last
+ * rm_frame_device / rm_render_frame call (first launch -> end of the last
+ * one), measured with HIP events on the stream they ran on (synchronises).
+ * launches = number of render kernel launches in that interval. */
 int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
 
 /* Device-vs-host checks of the float primitives the parity contract rests on.

@@ -24,7 +24,8 @@ EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_destroy",
     "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
-    "rm_render_frame", "rm_frame_device", "rm_last_frame_timing", "rm_selftest_prims",
+    "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_selftest_prims",
 ]
 
 
@@ -75,6 +76,17 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RmError(-2, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7
+    # (+ HSA runtime).  If this library pulled in /opt/rocm's copy first, torch
+    # would later load a second runtime and find "No HIP GPUs".  Importing torch
+    # first makes its copy the one our DT_NEEDED libamdhip64.so.7 binds to, so
+    # torch tensors, torch streams and these kernels share one runtime.  Set
+    # RAYMARCH_NO_TORCH=1 for a torch-free process (binds /opt/rocm's runtime).
+    if os.environ.get("RAYMARCH_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     L.rm_last_error.restype = ctypes.c_char_p
     L.rm_create.argtypes = [_i, ctypes.POINTER(_vp)]
@@ -89,7 +101,10 @@ def lib():
     L.rm_render_image_counted.argtypes = [_vp, _vp, _vp, _vp, _i, ctypes.POINTER(Counters)]
     L.rm_tonemap_image.argtypes = [_vp, _vp, _vp, _vp, _i]
     L.rm_render_frame.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
-    L.rm_frame_device.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]
+    L.rm_tiles_per_part.argtypes = [_i, _i, _i]
+    L.rm_frame_device.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    L.rm_resolve_device.argtypes = [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]
+    L.rm_check_device_opts.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
     L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
     _lib = L
@@ -200,10 +215,17 @@ class Context:
         return pixels, argb
 
     # -- device-resident pipeline ----------------------------------------
-    def frame_device(self, d_opts, d_mc, iters, n, d_pixels, d_argb=None, tile_first=0,
-                     tile_stride=1):
-        check(lib().rm_frame_device(self._h, d_opts, d_mc, iters, n, tile_first, tile_stride,
-                                    d_pixels, d_argb))
+    def frame_device(self, d_opts, d_mc, iters, n, width, d_tiles, tile_first=0, tile_stride=1):
+        """All passes of partition (tile_first, tile_stride) into its tile-major
+        accumulators (device pointers as ints); asynchronous."""
+        check(lib().rm_frame_device(self._h, d_opts, d_mc, iters, n, width, tile_first, tile_stride,
+                                    d_tiles))
+
+    def resolve_device(self, d_tiles_all, parts, d_opts, n, width, d_pixels=None, d_argb=None):
+        check(lib().rm_resolve_device(self._h, d_tiles_all, parts, d_opts, n, width, d_pixels, d_argb))
+
+    def check_device_opts(self, d_opts, iters, n, width):
+        check(lib().rm_check_device_opts(self._h, d_opts, iters, n, width))
 
     def last_frame_timing(self):
         ms = ctypes.c_float()
@@ -224,3 +246,10 @@ class Context:
 
 def device_count():
     return int(lib().rm_device_count())
+
+
+def tiles_per_part(width, n, parts):
+    r = int(lib().rm_tiles_per_part(width, n, parts))
+    if r < 0:
+        check(r)
+    return r

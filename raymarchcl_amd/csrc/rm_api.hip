@@ -64,7 +64,7 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
-  DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, cnt_buf, prim_a, prim_b, prim_o;
+  DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
   int rx = 0, ry = 0, rz = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -121,7 +121,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   memcpy(&o, opts544, sizeof o);
   HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
-                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, d_cnt));
+                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
   rm_counters got{};
   if (counters)
@@ -136,17 +136,17 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
 }
 
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
-                    int tile_first, int tile_stride, float* d_pixels, uint32_t* d_argb) {
+                    int tile_first, int tile_stride, float* d_tiles) {
+  const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), tile_stride);
+  HIP_TRY(hipMemsetAsync(d_tiles, 0, (size_t)tpp * 64 * 16, c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(hipMemsetAsync(d_pixels, 0, (size_t)n * 16, c->stream));
   for (int i = 0; i < iter; i++)
     HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, d_mc + (size_t)i * RM_TABLE_FLOATS,
-                                    d_opts + i, resx, d_pixels, n, 0, n, tile_first, tile_stride,
-                                    nullptr));
-  if (d_argb) HIP_TRY(rmk::launch_tonemap(c->stream, d_pixels, d_opts, d_argb, n));
+                                    d_opts + i, resx, d_tiles, n, 0, n, tile_first, tile_stride,
+                                    true, nullptr));
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->timed = true;
-  c->launches = iter + (d_argb ? 1 : 0);
+  c->launches = iter;
   return RM_OK;
 }
 
@@ -200,7 +200,7 @@ void rm_destroy(rm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf,
+  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf,
                     &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
   for (DevBuf* b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -312,11 +312,16 @@ int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, in
                          hipMemcpyHostToDevice, c->stream));
   RmOpts o0;
   memcpy(&o0, opts_array, sizeof o0);
+  const int tiles = rmk::tiles_total(o0.resolution[0], n);
+  HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
   rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
                        static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
-                       static_cast<float*>(c->pix_buf.p),
-                       argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr);
+                       static_cast<float*>(c->tile_buf.p));
   if (rc) return rc;
+  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
+                              static_cast<const RmOpts*>(c->opts_buf.p),
+                              pixels_out ? static_cast<float*>(c->pix_buf.p) : nullptr,
+                              argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr, n));
   if (pixels_out)
     HIP_TRY(hipMemcpyAsync(pixels_out, c->pix_buf.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
   if (argb_out)
@@ -325,23 +330,52 @@ int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, in
   return RM_OK;
 }
 
-int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, int n,
-                    int tile_first, int tile_stride, float* d_pixels, uint32_t* d_argb) {
+int rm_tiles_per_part(int resx, int n, int parts) {
+  if (resx <= 0 || n < 0 || parts < 1) return fail(RM_EINVAL, "rm_tiles_per_part(%d,%d,%d)", resx, n, parts);
+  return rmk::tiles_per_part(rmk::tiles_total(resx, n), parts);
+}
+
+int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int width) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!d_opts || !d_mc || !d_pixels) return fail(RM_EINVAL, "NULL device buffer");
-  if (iter <= 0 || n <= 0) return fail(RM_EINVAL, "iter = %d, n = %d", iter, n);
+  if (!d_opts || iter <= 0) return fail(RM_EINVAL, "d_opts NULL or iter = %d", iter);
+  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  for (int i = 0; i < iter; i++) {
+    RmOpts o;
+    HIP_TRY(hipMemcpyAsync(&o, static_cast<const char*>(d_opts) + (size_t)i * RM_OPTS_BYTES, sizeof o,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = check_opts(c, &o, n);
+    if (rc) return rc;
+    if (o.resolution[0] != width)
+      return fail(RM_EINVAL, "record %d: resolution.x = %d but width = %d", i, o.resolution[0], width);
+  }
+  return RM_OK;
+}
+
+int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, int n, int width,
+                    int tile_first, int tile_stride, float* d_tiles) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_opts || !d_mc || !d_tiles) return fail(RM_EINVAL, "NULL device buffer");
+  if (iter <= 0 || n <= 0 || width <= 0) return fail(RM_EINVAL, "iter = %d, n = %d, width = %d", iter, n, width);
   if (tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
     return fail(RM_EINVAL, "tile partition (%d,%d)", tile_first, tile_stride);
   if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
-  // resolution.x is needed on the host to size the grid: fetch opts[0] once.
-  RmOpts o0;
-  HIP_TRY(hipMemcpyAsync(&o0, d_opts, sizeof o0, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  rc = check_opts(c, &o0, n);
+  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, tile_first,
+                         tile_stride, d_tiles);
+}
+
+int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void* d_opts, int n,
+                      int width, float* d_pixels, uint32_t* d_argb) {
+  int rc = check_ctx(c);
   if (rc) return rc;
-  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, o0.resolution[0], iter, n,
-                         tile_first, tile_stride, d_pixels, d_argb);
+  if (!d_tiles_all || !d_opts) return fail(RM_EINVAL, "NULL device buffer");
+  if (parts < 1 || n <= 0 || width <= 0) return fail(RM_EINVAL, "parts = %d, n = %d, width = %d", parts, n, width);
+  const int tpp = rmk::tiles_per_part(rmk::tiles_total(width, n), parts);
+  HIP_TRY(rmk::launch_resolve(c->stream, d_tiles_all, parts, tpp, static_cast<const RmOpts*>(d_opts),
+                              d_pixels, d_argb, n));
+  return RM_OK;
 }
 
 int rm_last_frame_timing(rm_ctx* c, float* ms, int* launches) {

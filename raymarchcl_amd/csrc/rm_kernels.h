@@ -13,7 +13,12 @@ int tiles_total(int resx, int n);
 
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
-                              int id1, int tile_first, int tile_stride, Counters* d_counters);
+                              int id1, int tile_first, int tile_stride, bool tile_major,
+                              Counters* d_counters);
+// tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
+inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / parts; }
+hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
+                          const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
                           uint32_t* d_argb, int n);
 hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,

@@ -46,7 +46,11 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
   return (int)id;
 }
 
-template <bool COUNT>
+// TILE_MAJOR: the accumulator is stored tile by tile (slot*64 + lane, one
+// contiguous 1 KiB store per wave) instead of at the work-item id; used by the
+// device-resident pipeline and the multi-GPU partition, un-permuted by
+// resolve_kernel.
+template <bool COUNT, bool TILE_MAJOR>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
     const uint8_t* __restrict__ vox, const float4* __restrict__ mc, const RmOpts* __restrict__ opts,
     float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
@@ -63,9 +67,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
     const float fb = opts->frameBlend;
-    const float4 p = pixels[id];
+    const long long at = TILE_MAJOR ? slot * 64 + lane : (long long)id;
+    const float4 p = pixels[at];
     // mix(p, col, frameBlend): renderer.cl:492
-    pixels[id] = make_float4(p.x + (col.x - p.x) * fb, p.y + (col.y - p.y) * fb,
+    pixels[at] = make_float4(p.x + (col.x - p.x) * fb, p.y + (col.y - p.y) * fb,
                              p.z + (col.z - p.z) * fb, 1.0f);
   }
   if (COUNT) {
@@ -94,6 +99,38 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
       ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
     }
     argb[id] = 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
+  }
+}
+
+// Tile-major accumulators of `parts` interleaved partitions (partition r owns
+// tiles r, r+parts, ...; each partition's buffer holds tiles_per_part tiles of
+// 64 float4) -> row-major float4 pixels and/or tonemapped ARGB.
+__global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__ tiles, int parts,
+                                                      int tiles_per_part,
+                                                      const RmOpts* __restrict__ opts,
+                                                      float4* __restrict__ pixels,
+                                                      uint32_t* __restrict__ argb, int n) {
+  const int resx = opts->resolution[0];
+  const int tiles_x = (resx + kTile - 1) / kTile;
+  const float g = opts->gamma;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n;
+       id += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(id % resx), y = (int)(id / resx);
+    const int tile = (y >> 3) * tiles_x + (x >> 3);
+    const int lane = ((y & 7) << 3) | (x & 7);
+    const long long at = ((long long)(tile % parts) * tiles_per_part + tile / parts) * 64 + lane;
+    const float4 p = tiles[at];
+    if (pixels) pixels[id] = p;
+    if (argb) {
+      const float c[3] = {p.x, p.y, p.z};
+      uint32_t ch[3];
+      for (int k = 0; k < 3; k++) {
+        const float t = c[k] / (g + c[k]);
+        const float v = t * t * 255.0f;
+        ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
+      }
+      argb[id] = 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
+    }
   }
 }
 
@@ -127,21 +164,26 @@ int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
-                              int id1, int tile_first, int tile_stride, Counters* d_counters) {
+                              int id1, int tile_first, int tile_stride, bool tile_major,
+                              Counters* d_counters) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const long long my_tiles =
       tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
   if (my_tiles == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((my_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  const float4* mc4 = reinterpret_cast<const float4*>(mc);
+  float4* px4 = reinterpret_cast<float4*>(pixels);
+  const dim3 grid(blocks), block(64 * kWavesPerBlock);
   if (d_counters)
-    render_pass_kernel<true><<<blocks, 64 * kWavesPerBlock, 0, st>>>(
-        vox, reinterpret_cast<const float4*>(mc), d_opts, reinterpret_cast<float4*>(pixels), n, id0,
-        id1, tile_first, tile_stride, d_counters);
+    render_pass_kernel<true, false><<<grid, block, 0, st>>>(vox, mc4, d_opts, px4, n, id0, id1,
+                                                            tile_first, tile_stride, d_counters);
+  else if (tile_major)
+    render_pass_kernel<false, true><<<grid, block, 0, st>>>(vox, mc4, d_opts, px4, n, id0, id1,
+                                                            tile_first, tile_stride, nullptr);
   else
-    render_pass_kernel<false><<<blocks, 64 * kWavesPerBlock, 0, st>>>(
-        vox, reinterpret_cast<const float4*>(mc), d_opts, reinterpret_cast<float4*>(pixels), n, id0,
-        id1, tile_first, tile_stride, nullptr);
+    render_pass_kernel<false, false><<<grid, block, 0, st>>>(vox, mc4, d_opts, px4, n, id0, id1,
+                                                             tile_first, tile_stride, nullptr);
   return hipGetLastError();
 }
 
@@ -151,6 +193,17 @@ hipError_t launch_tonemap(hipStream_t st, const float* pixels, const RmOpts* d_o
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   tonemap_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve(hipStream_t st, const float* tiles, int parts, int tiles_per_part,
+                          const RmOpts* d_opts0, float* pixels, uint32_t* argb, int n) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  resolve_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts,
+                                         tiles_per_part, d_opts0, reinterpret_cast<float4*>(pixels),
+                                         argb, n);
   return hipGetLastError();
 }
 

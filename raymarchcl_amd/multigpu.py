@@ -1,0 +1,132 @@
+"""Image-tile partition of one frame over the GPUs of a node.
+
+Not a reference feature (the reference drives a single device, core.clj:122);
+it is BASELINE.json's multi-GPU requirement.  Every work-item of the render
+kernel depends only on its own global id (renderer.cl:469-473, 267, 334), so
+any partition of the image gives bit-identical pixels.  Layout:
+
+* the image is cut into 8x8-pixel tiles, numbered row-major;
+* rank r of ``world`` owns tiles r, r+world, r+2*world, ... (interleaved,
+  because cost per tile is very uneven: sky vs. multi-bounce surfaces);
+* a rank keeps its accumulators tile-major -- ``tiles_per_part`` tiles of 64
+  float4 -- which is also the unit that is exchanged;
+* ONE collective per frame: gather of the tile-major accumulators to rank 0
+  (torch.distributed -> RCCL over xGMI: point-to-point sends into the root, all
+  links concurrently); the root un-permutes + tonemaps (rm_resolve_device).
+
+The volume, the scatter tables and the option records are replicated.
+"""
+import numpy as np
+
+TILE = 8
+TILE_PIXELS = TILE * TILE
+
+
+def tile_geometry(width, n):
+    """-> (tiles_x, tiles_total) covering work-items 0..n-1 of an image ``width`` wide."""
+    rows = -(-n // width)
+    tiles_x = -(-width // TILE)
+    return tiles_x, tiles_x * (-(-rows // TILE))
+
+
+def tiles_per_part(width, n, world):
+    return -(-tile_geometry(width, n)[1] // world)
+
+
+def owner_of_tile(tile, world):
+    """-> (rank, local tile index)"""
+    return tile % world, tile // world
+
+
+def gathered_index_map(width, n, world):
+    """For every work-item id < n: its float4 index in the gathered buffer
+    ``[world][tiles_per_part][64]``.  Host mirror of what resolve_kernel
+    computes on the device (used by the CPU tests and to check the kernel)."""
+    tiles_x, _total = tile_geometry(width, n)
+    tpp = tiles_per_part(width, n, world)
+    ids = np.arange(n, dtype=np.int64)
+    x, y = ids % width, ids // width
+    tile = (y // TILE) * tiles_x + (x // TILE)
+    lane = (y % TILE) * TILE + (x % TILE)
+    return ((tile % world) * tpp + tile // world) * TILE_PIXELS + lane
+
+
+def local_work_items(width, n, rank, world):
+    """-> (ids, local float4 index) of the work-items rank owns (ids < n only)."""
+    idx = gathered_index_map(width, n, world)
+    tpp = tiles_per_part(width, n, world)
+    lo, hi = rank * tpp * TILE_PIXELS, (rank + 1) * tpp * TILE_PIXELS
+    mine = np.nonzero((idx >= lo) & (idx < hi))[0]
+    return mine, idx[mine] - lo
+
+
+def gather_tiles(local_tiles, rank, world, dst=0, group=None):
+    """Gather every rank's tile-major accumulators on ``dst``.
+
+    local_tiles: float32 tensor [tiles_per_part*64*4] (CPU with gloo, GPU with
+    nccl == RCCL).  Returns the [world * tiles_per_part*64*4] tensor on ``dst``,
+    None elsewhere.  world == 1 returns the input.
+    """
+    if world == 1:
+        return local_tiles
+    import torch
+    import torch.distributed as dist
+
+    if rank == dst:
+        out = torch.empty(world * local_tiles.numel(), dtype=local_tiles.dtype,
+                          device=local_tiles.device)
+        chunks = list(out.view(world, -1).unbind(0))
+        dist.gather(local_tiles, gather_list=chunks, dst=dst, group=group)
+        return out
+    dist.gather(local_tiles, gather_list=None, dst=dst, group=group)
+    return None
+
+
+class FrameRenderer:
+    """Device-resident pipeline of one rank: inputs live in HBM as torch
+    tensors, kernels run on torch's current stream, and ``render()`` does
+    rm_frame_device -> (gather) -> rm_resolve_device on the root."""
+
+    def __init__(self, vox, vres, opts_bytes, mc, n, width, rank=0, world=1, device=None,
+                 want_pixels=True, want_argb=True, group=None):
+        import torch
+
+        from . import _native
+
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        self.n, self.width = int(n), int(width)
+        self.iters = len(opts_bytes) // _native.OPTS_BYTES
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        dev = self.device
+        self.d_vox = torch.from_numpy(np.ascontiguousarray(vox)).to(dev)
+        self.d_opts = torch.frombuffer(bytearray(opts_bytes), dtype=torch.uint8).to(dev)
+        self.d_mc = torch.from_numpy(np.ascontiguousarray(mc, dtype=np.float32).reshape(-1)).to(dev)
+        assert self.d_mc.numel() == self.iters * _native.TABLE_FLOATS
+        self.tpp = _native.tiles_per_part(self.width, self.n, world)
+        assert self.tpp == tiles_per_part(self.width, self.n, world)
+        self.d_tiles = torch.zeros(self.tpp * TILE_PIXELS * 4, dtype=torch.float32, device=dev)
+        root = rank == 0
+        self.d_pixels = torch.empty(4 * self.n, dtype=torch.float32, device=dev) if (root and want_pixels) else None
+        self.d_argb = torch.empty(self.n, dtype=torch.int32, device=dev) if (root and want_argb) else None
+        self.ctx = _native.Context(dev.index or 0)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        self.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
+        self.ctx.check_device_opts(self.d_opts.data_ptr(), self.iters, self.n, self.width)
+        torch.cuda.synchronize(dev)
+
+    def render(self):
+        """One frame.  Asynchronous; results are valid on the root after a
+        stream synchronise."""
+        self.ctx.frame_device(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
+                              self.width, self.d_tiles.data_ptr(), self.rank, self.world)
+        allt = gather_tiles(self.d_tiles, self.rank, self.world, group=self.group)
+        if self.rank == 0:
+            self.ctx.resolve_device(allt.data_ptr(), self.world, self.d_opts.data_ptr(), self.n,
+                                    self.width,
+                                    self.d_pixels.data_ptr() if self.d_pixels is not None else None,
+                                    self.d_argb.data_ptr() if self.d_argb is not None else None)
+        return self.d_pixels, self.d_argb
+
+    def close(self):
+        self.ctx.close()

@@ -122,19 +122,49 @@ def test_config2_sampled_against_oracle_and_partition_invariance(gpu_ctx, oracle
                                     want, n=n, id0=lo, id1=hi, threads=1)
     assert _eq(px.reshape(-1, 4)[ids], want.reshape(-1, 4)[ids])
     assert np.array_equal(argb[ids], oracle_mod.tonemap_image(want, sc["opts"][:544], n=n)[ids])
-    # tile partition (the multi-GPU split): union of 3 interleaved partitions == full frame
+    # tile partition (the multi-GPU split): 3 interleaved partitions, "gathered" by
+    # concatenation, resolved on the device == the full frame
+    from raymarchcl_amd import multigpu
+
     dev = torch.device("cuda:0")
     d_opts = torch.frombuffer(bytearray(sc["opts"]), dtype=torch.uint8).to(dev)
     d_mc = torch.from_numpy(sc["mc"]).to(dev)
-    acc = np.zeros(4 * n, np.float32)
-    for r in range(3):
-        d_px = torch.empty(4 * n, dtype=torch.float32, device=dev)
-        gpu_ctx.frame_device(d_opts.data_ptr(), d_mc.data_ptr(), it, n, d_px.data_ptr(), None, r, 3)
-        gpu_ctx.synchronize()
-        part = d_px.cpu().numpy()
-        assert not (np.logical_and(part != 0, acc != 0)).any()  # partitions are disjoint
-        acc += part
-    assert _eq(acc, px)
+    parts = 3
+    tpp = multigpu.tiles_per_part(sc["w"], n, parts)
+    d_all = torch.zeros(parts * tpp * 64 * 4, dtype=torch.float32, device=dev)
+    gpu_ctx.check_device_opts(d_opts.data_ptr(), it, n, sc["w"])
+    for r in range(parts):
+        part = d_all[r * tpp * 256:(r + 1) * tpp * 256]
+        gpu_ctx.frame_device(d_opts.data_ptr(), d_mc.data_ptr(), it, n, sc["w"], part.data_ptr(), r, parts)
+    d_px = torch.empty(4 * n, dtype=torch.float32, device=dev)
+    d_argb = torch.empty(n, dtype=torch.int32, device=dev)
+    gpu_ctx.resolve_device(d_all.data_ptr(), parts, d_opts.data_ptr(), n, sc["w"], d_px.data_ptr(),
+                           d_argb.data_ptr())
+    gpu_ctx.synchronize()
+    assert _eq(d_px.cpu().numpy(), px)
+    assert np.array_equal(d_argb.cpu().numpy().view(np.uint32), argb)
+    # the host mirror of the un-permute agrees with the kernel
+    idx = multigpu.gathered_index_map(sc["w"], n, parts)
+    assert _eq(d_all.cpu().numpy().reshape(-1, 4)[idx].reshape(-1), px)
+
+
+def test_frame_renderer_single_gpu(gpu_ctx, config2):
+    """The torch-resident pipeline object bench.py uses == the host-buffer API."""
+    import torch
+
+    from raymarchcl_amd import multigpu
+
+    sc = config2
+    gpu_ctx.set_volume(sc["vox"], sc["vres"])
+    px, argb = gpu_ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+    fr = multigpu.FrameRenderer(sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"], sc["w"])
+    d_px, d_argb = fr.render()
+    torch.cuda.synchronize()
+    assert _eq(d_px.cpu().numpy(), px)
+    assert np.array_equal(d_argb.cpu().numpy().view(np.uint32), argb)
+    ms, launches = fr.ctx.last_frame_timing()
+    assert launches == sc["iter"] and ms > 0
+    fr.close()
 
 
 def _runs(ids):
