@@ -121,7 +121,9 @@ int rm_resolve_device(rm_ctx* ctx, const float* d_tiles_all, int parts, const vo
  * read the records back (no host<->device traffic per frame); `width` must be
  * TRenderOpts.resolution.x.  This synchronous helper fetches the `iter` records
  * once and applies the same validation the host-buffer entry points do
- * (resolution, voxelRes against the resident volume, numLights). */
+ * (resolution, voxelRes against the resident volume, numLights), and notes each
+ * record's isoVal; rm_frame_device refuses d_opts that were not checked.  Call
+ * it again after rewriting the records in place. */
 int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int width);
 
 /* Elapsed milliseconds of the RenderImage-pass kernels of the last
@@ -129,6 +131,14 @@ int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int w
  * one), measured with HIP events on the stream they ran on (synchronises).
  * launches = number of render kernel launches in that interval. */
 int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
+
+/* Test hook: copy out the derived structures the kernels use for the resident
+ * volume at hit threshold `iso` (see csrc/rm_accel.hip): dist_out = rx*ry*rz
+ * bytes (0 = cell the march hits, else Chebyshev distance to the nearest hit
+ * cell or grid edge, capped at 255), surf_out = rx*ry*rz uint32 (packed voxel
+ * value + smooth/flat normal terms; meaningful where value > iso).  Either
+ * pointer may be NULL. */
+int rm_debug_get_accel(rm_ctx* ctx, int iso, uint8_t* dist_out, uint32_t* surf_out);
 
 /* Device-vs-host checks of the float primitives the parity contract rests on.
  * op: 0 a/b, 1 sqrt(a), 2 exp(a), 3 exp2(a), 4 pow(a,b), 5 (int)a [x86],

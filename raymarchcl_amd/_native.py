@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libraymarch_hip.so")
-SOURCES = ["rm_kernels.hip", "rm_api.hip"]
+SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_api.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 OPTS_BYTES = 544
@@ -25,7 +25,7 @@ EXPORTS = [
     "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_selftest_prims",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_selftest_prims",
 ]
 
 
@@ -107,6 +107,7 @@ def lib():
     L.rm_check_device_opts.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
     L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
+    L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
     _lib = L
     return L
 
@@ -232,6 +233,13 @@ class Context:
         k = _i()
         check(lib().rm_last_frame_timing(self._h, ctypes.byref(ms), ctypes.byref(k)))
         return float(ms.value), int(k.value)
+
+    def debug_get_accel(self, iso):
+        nvox = int(np.prod(self.vres))
+        dist = np.zeros(nvox, dtype=np.uint8)
+        surf = np.zeros(nvox, dtype=np.uint32)
+        check(lib().rm_debug_get_accel(self._h, iso, dist.ctypes.data, surf.ctypes.data))
+        return dist, surf
 
     def selftest_prims(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)

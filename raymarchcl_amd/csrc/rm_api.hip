@@ -8,8 +8,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/raymarch_hip.h"
 #include "rm_kernels.h"
@@ -65,6 +67,11 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
+  DevBuf dist_buf, tmp_buf, surf_buf;  // rm_accel.hip structures of the resident volume
+  int accel_iso = -1;                  // isoVal they were built for, -1 = stale
+  bool use_accel = true;               // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
+  std::vector<int> dev_iso;            // isoVal per record, noted by rm_check_device_opts
+  const void* dev_iso_src = nullptr;
   int rx = 0, ry = 0, rz = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -95,6 +102,25 @@ int check_opts(rm_ctx* c, const void* opts544, int n) {
   return RM_OK;
 }
 
+// Build (or reuse) dist8/surf32 for the hit threshold of this launch.
+int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
+  *out = rmk::Accel{};
+  if (!c->use_accel) return RM_OK;
+  const size_t vox = (size_t)c->rx * c->ry * c->rz;
+  if (c->accel_iso != iso) {
+    HIP_TRY(c->dist_buf.reserve(vox));
+    HIP_TRY(c->tmp_buf.reserve(vox));
+    HIP_TRY(c->surf_buf.reserve(vox * 4));
+    HIP_TRY(rmk::build_accel(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso,
+                             static_cast<uint8_t*>(c->dist_buf.p), static_cast<uint8_t*>(c->tmp_buf.p),
+                             static_cast<uint32_t*>(c->surf_buf.p)));
+    c->accel_iso = iso;
+  }
+  out->dist = static_cast<const uint8_t*>(c->dist_buf.p);
+  out->surf = static_cast<const uint32_t*>(c->surf_buf.p);
+  return RM_OK;
+}
+
 int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n, int id0,
                      int id1, rm_counters* counters) {
   int rc = check_ctx(c);
@@ -119,7 +145,10 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   }
   RmOpts o;
   memcpy(&o, opts544, sizeof o);
-  HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, static_cast<const float*>(c->mc_buf.p),
+  rmk::Accel accel;
+  rc = ensure_accel(c, o.isoVal, &accel);
+  if (rc) return rc;
+  HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
                                   static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -136,14 +165,18 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
 }
 
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
-                    int tile_first, int tile_stride, float* d_tiles) {
+                    int tile_first, int tile_stride, float* d_tiles, const int* iso_per_pass) {
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), tile_stride);
   HIP_TRY(hipMemsetAsync(d_tiles, 0, (size_t)tpp * 64 * 16, c->stream));
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  for (int i = 0; i < iter; i++)
-    HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, d_mc + (size_t)i * RM_TABLE_FLOATS,
+  for (int i = 0; i < iter; i++) {
+    rmk::Accel accel;
+    int rc = ensure_accel(c, iso_per_pass[i], &accel);
+    if (rc) return rc;
+    HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, accel, d_mc + (size_t)i * RM_TABLE_FLOATS,
                                     d_opts + i, resx, d_tiles, n, 0, n, tile_first, tile_stride,
                                     true, nullptr));
+  }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->timed = true;
   c->launches = iter;
@@ -192,6 +225,8 @@ int rm_create(int device_id, rm_ctx** out) {
     return fail(RM_EDEVICE, "stream/event creation: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  const char* na = getenv("RAYMARCH_NO_ACCEL");
+  c->use_accel = !(na && na[0] == '1');
   *out = c;
   return RM_OK;
 }
@@ -200,7 +235,7 @@ void rm_destroy(rm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf,
+  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf,
                     &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
   for (DevBuf* b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -243,6 +278,7 @@ int rm_set_volume(rm_ctx* c, const uint8_t* voxels, int rx, int ry, int rz) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
   c->rx = rx; c->ry = ry; c->rz = rz;
+  c->accel_iso = -1;
   return RM_OK;
 }
 
@@ -254,6 +290,7 @@ int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz
   if (rc) return rc;
   c->d_vox = static_cast<const uint8_t*>(d_voxels);
   c->rx = rx; c->ry = ry; c->rz = rz;
+  c->accel_iso = -1;
   return RM_OK;
 }
 
@@ -314,9 +351,12 @@ int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, in
   memcpy(&o0, opts_array, sizeof o0);
   const int tiles = rmk::tiles_total(o0.resolution[0], n);
   HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
+  std::vector<int> isos(iter);
+  for (int i = 0; i < iter; i++)
+    isos[i] = static_cast<const uint8_t*>(opts_array)[(size_t)i * RM_OPTS_BYTES + offsetof(RmOpts, isoVal)];
   rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
                        static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
-                       static_cast<float*>(c->tile_buf.p));
+                       static_cast<float*>(c->tile_buf.p), isos.data());
   if (rc) return rc;
   HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
                               static_cast<const RmOpts*>(c->opts_buf.p),
@@ -349,7 +389,10 @@ int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int wid
     if (rc) return rc;
     if (o.resolution[0] != width)
       return fail(RM_EINVAL, "record %d: resolution.x = %d but width = %d", i, o.resolution[0], width);
+    if (i == 0) c->dev_iso.clear();
+    c->dev_iso.push_back(o.isoVal);
   }
+  c->dev_iso_src = d_opts;
   return RM_OK;
 }
 
@@ -362,8 +405,10 @@ int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, 
   if (tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
     return fail(RM_EINVAL, "tile partition (%d,%d)", tile_first, tile_stride);
   if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (c->dev_iso_src != d_opts || (int)c->dev_iso.size() != iter)
+    return fail(RM_ESTATE, "rm_check_device_opts(d_opts, iter=%d, ...) must validate the records first", iter);
   return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, tile_first,
-                         tile_stride, d_tiles);
+                         tile_stride, d_tiles, c->dev_iso.data());
 }
 
 int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void* d_opts, int n,
@@ -387,6 +432,22 @@ int rm_last_frame_timing(rm_ctx* c, float* ms, int* launches) {
   HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
   if (ms) *ms = t;
   if (launches) *launches = c->launches;
+  return RM_OK;
+}
+
+int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (iso < 0 || iso > 255) return fail(RM_EINVAL, "iso = %d", iso);
+  if (!c->use_accel) return fail(RM_ESTATE, "acceleration structures are disabled (RAYMARCH_NO_ACCEL)");
+  rmk::Accel accel;
+  rc = ensure_accel(c, iso, &accel);
+  if (rc) return rc;
+  const size_t vox = (size_t)c->rx * c->ry * c->rz;
+  if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
+  if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }
 

@@ -11,7 +11,11 @@ struct Counters;
 // number of 8x8 tiles covering work-items 0..n-1 of an image `resx` wide
 int tiles_total(int resx, int n);
 
-hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, const float* d_mc,
+struct Accel {  // nullptrs = not available: the kernels then run the plain fixed-step march
+  const uint8_t* dist = nullptr;
+  const uint32_t* surf = nullptr;
+};
+hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
                               Counters* d_counters);
@@ -21,6 +25,10 @@ hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int t
                           const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
                           uint32_t* d_argb, int n);
+// dist8 / surf32 of a resident volume for hit threshold `iso` (rm_accel.hip);
+// d_tmp is scratch of the volume's size.
+hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
+                       uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf);
 hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,
                         int n);
 }  // namespace rmk

@@ -50,9 +50,11 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
 // contiguous 1 KiB store per wave) instead of at the work-item id; used by the
 // device-resident pipeline and the multi-GPU partition, un-permuted by
 // resolve_kernel.
-template <bool COUNT, bool TILE_MAJOR>
+template <bool COUNT, bool TILE_MAJOR, bool ACCEL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
-    const uint8_t* __restrict__ vox, const float4* __restrict__ mc, const RmOpts* __restrict__ opts,
+    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
+    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
+    const RmOpts* __restrict__ opts,
     float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
     rmk::Counters* __restrict__ counters) {
   const int resx = opts->resolution[0];
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   const long long tile = tile_first + slot * tile_stride;
   if (tile >= g.tiles_total) return;
   const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
-  rmk::Scene sc{vox, mc, opts};
-  rmk::Tracer<COUNT> tr(sc);
+  rmk::Scene sc{vox, mc, opts, dist8, surf32};
+  rmk::Tracer<COUNT, ACCEL> tr(sc);
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
     const float fb = opts->frameBlend;
@@ -162,7 +164,7 @@ namespace rmk {
 
 int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
-hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, const float* mc,
+hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
                               Counters* d_counters) {
@@ -175,15 +177,17 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, const float* m
   const float4* mc4 = reinterpret_cast<const float4*>(mc);
   float4* px4 = reinterpret_cast<float4*>(pixels);
   const dim3 grid(blocks), block(64 * kWavesPerBlock);
-  if (d_counters)
-    render_pass_kernel<true, false><<<grid, block, 0, st>>>(vox, mc4, d_opts, px4, n, id0, id1,
-                                                            tile_first, tile_stride, d_counters);
-  else if (tile_major)
-    render_pass_kernel<false, true><<<grid, block, 0, st>>>(vox, mc4, d_opts, px4, n, id0, id1,
-                                                            tile_first, tile_stride, nullptr);
-  else
-    render_pass_kernel<false, false><<<grid, block, 0, st>>>(vox, mc4, d_opts, px4, n, id0, id1,
-                                                             tile_first, tile_stride, nullptr);
+  const bool acc = accel.dist && accel.surf;
+#define RM_LAUNCH(C, T, A)                                                                      \
+  render_pass_kernel<C, T, A><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, \
+                                                      px4, n, id0, id1, tile_first, tile_stride, \
+                                                      d_counters)
+  if (d_counters) RM_LAUNCH(true, false, false);
+  else if (tile_major && acc) RM_LAUNCH(false, true, true);
+  else if (tile_major) RM_LAUNCH(false, true, false);
+  else if (acc) RM_LAUNCH(false, false, true);
+  else RM_LAUNCH(false, false, false);
+#undef RM_LAUNCH
   return hipGetLastError();
 }
 

@@ -52,10 +52,40 @@ struct Scene {
   const uint8_t* __restrict__ vox;
   const float4* __restrict__ mc;
   const RmOpts* __restrict__ o;
+  const uint8_t* __restrict__ dist;   // rm_accel.hip dist8, or nullptr
+  const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
 };
 
-template <bool COUNT>
+// Exact multi-step advance of the fixed-step march (used with dist8).
+//
+// The reference walks p <- fl(p + delta) once per sample.  While a component
+// stays inside one binade [2^e, 2^(e+1)) every add rounds to the same grid of
+// spacing u = 2^(e-23), so the rounded increment D = fl(p+delta) - p is a
+// CONSTANT multiple of u (the only exception, an exact tie, settles after one
+// add), and k further adds land exactly on p + k*D, which float arithmetic
+// evaluates without error (both k*D and the sum are multiples of u below
+// 2^24 u).  advance_exact() therefore takes two real adds, measures D on the
+// second, and jumps the remaining k-2 samples in one step -- provided start,
+// warm-up and landing points share their binade component-wise; otherwise it
+// reports failure and the caller falls back to single adds.
+RM_DEV bool same_binade(float a, float b) {
+  return ((__float_as_uint(a) ^ __float_as_uint(b)) & 0xff800000u) == 0u;  // sign + exponent
+}
+RM_DEV bool advance_exact(v3& p, v3 delta, int k) {
+  const v3 p1 = p + delta;
+  const v3 p2 = p1 + delta;
+  const v3 D = p2 - p1;
+  const float m = (float)(k - 2);
+  const v3 q = V(p2.x + m * D.x, p2.y + m * D.y, p2.z + m * D.z);
+  const bool ok = same_binade(p.x, p2.x) && same_binade(p.y, p2.y) && same_binade(p.z, p2.z) &&
+                  same_binade(p.x, q.x) && same_binade(p.y, q.y) && same_binade(p.z, q.z);
+  if (ok) p = q;
+  return ok;
+}
+
+template <bool COUNT, bool ACCEL = false>
 struct Tracer {
+  static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
   const Scene& sc;
   Counters cnt;  // per-lane, only touched when COUNT
   RM_DEV explicit Tracer(const Scene& s) : sc(s), cnt{} {}
@@ -144,6 +174,46 @@ struct Tracer {
       p = p * ivs;
       const float frx = (float)o.voxelRes[0], fry = (float)o.voxelRes[1], frz = (float)o.voxelRes[2];
       const int iso = o.isoVal;
+      if (ACCEL) {
+        // cells per sample along the fastest axis, padded: bounds how many samples
+        // certainly stay inside the empty neighbourhood dist8 reports
+        const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
+                              __builtin_fabsf(delta.z) * frz);
+        const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
+        while (steps > 0) {
+          const int qx = rmd::convert_int_sat(p.x * frx);
+          const int qy = rmd::convert_int_sat(p.y * fry);
+          const int qz = rmd::convert_int_sat(p.z * frz);
+          if (!in_grid(qx, qy, qz)) break;
+          const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
+          const int dcell = sc.dist[cell];
+          if (dcell == 0) {
+            const uint32_t w = sc.surf[cell];
+            const int v = (int)(w & 0xffu);
+            if (smooth) {
+              nrm = normalize(V((float)((int)((w >> 8) & 63u) - 32), (float)((int)((w >> 14) & 63u) - 32),
+                                (float)((int)((w >> 20) & 63u) - 32)));
+            } else {
+              nrm = normalize(V(-(float)((int)((w >> 26) & 3u) - 1), -(float)((int)((w >> 28) & 3u) - 1),
+                                -(float)((int)((w >> 30) & 3u) - 1)));
+            }
+            const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
+            const float d = length(rpos - hit) - o.voxelSize;
+            if (d < rd) { rd = d; rc = v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }
+            break;
+          }
+          // samples k = 1 .. j-1 from here are certainly in empty in-bounds cells
+          int j = (int)((float)(dcell - 2) * inv_s);
+          if (j >= 4 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
+            if (j >= steps) break;  // the walk ends before it can reach anything
+            if (advance_exact(p, delta, j)) { steps -= j; continue; }
+            j = j >> 2;
+            if (j >= 4 && advance_exact(p, delta, j)) { steps -= j; continue; }
+          }
+          p = p + delta;
+          steps -= 1;
+        }
+      } else
       while (--steps >= 0) {
         const int qx = rmd::convert_int_sat(p.x * frx);
         const int qy = rmd::convert_int_sat(p.y * fry);

@@ -1,0 +1,52 @@
+"""The derived structures (csrc/rm_accel.hip) against independent host
+computations: dist8 == chessboard distance transform (scipy) of the padded
+"hit or outside" mask, surf32 == voxel value + the normal terms the reference
+algorithm would sum (numpy)."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,vres,iso", [("gyroid", 64, 32), ("gyroid-crop", (64, 40, 48), 32),
+                                           ("terrain", 64, 32), ("blobs", 64, 100),
+                                           ("empty", 32, 32), ("solid", 32, 32)])
+def test_dist8_and_surf32(gpu_ctx, kind, vres, iso):
+    from scipy import ndimage
+
+    vox = scenes.volume(kind, vres)
+    rx, ry, rz = (vres,) * 3 if isinstance(vres, int) else vres
+    gpu_ctx.set_volume(vox, (rx, ry, rz))
+    dist, surf = gpu_ctx.debug_get_accel(iso)
+    g = vox.reshape(rz, ry, rx)
+    empty = np.zeros((rz + 2, ry + 2, rx + 2), dtype=bool)  # outside the grid counts as hit
+    empty[1:-1, 1:-1, 1:-1] = g <= iso
+    want = ndimage.distance_transform_cdt(empty, metric="chessboard")[1:-1, 1:-1, 1:-1]
+    want = np.minimum(want, 255).astype(np.uint8)
+    assert np.array_equal(dist.reshape(rz, ry, rx), want)
+    # surf32: value, flat central differences, smooth 3x3x3 sums (occupancy is v >= iso)
+    occ = np.zeros((rz + 4, ry + 4, rx + 4), dtype=np.int32)
+    occ[2:-2, 2:-2, 2:-2] = g >= iso
+    gx = occ[:, :, 2:] - occ[:, :, :-2]
+    gy = occ[:, 2:, :] - occ[:, :-2, :]
+    gz = occ[2:, :, :] - occ[:-2, :, :]
+    gx = gx[1:-1, 1:-1, :]; gy = gy[1:-1, :, 1:-1]; gz = gz[:, 1:-1, 1:-1]  # (rz+2, ry+2, rx+2)
+    o1 = occ[1:-1, 1:-1, 1:-1]
+    sx = np.zeros((rz, ry, rx), np.int32); sy = sx.copy(); sz = sx.copy()
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                sl = (slice(dz, dz + rz), slice(dy, dy + ry), slice(dx, dx + rx))
+                sx -= o1[sl] * gx[sl]; sy -= o1[sl] * gy[sl]; sz -= o1[sl] * gz[sl]
+    c = (slice(1, -1),) * 3
+    hit = g > iso
+    s = surf.reshape(rz, ry, rx)
+    assert np.array_equal(s & 0xff, g)
+    assert np.array_equal(((s >> 8) & 63).astype(np.int32)[hit] - 32, sx[hit])
+    assert np.array_equal(((s >> 14) & 63).astype(np.int32)[hit] - 32, sy[hit])
+    assert np.array_equal(((s >> 20) & 63).astype(np.int32)[hit] - 32, sz[hit])
+    assert np.array_equal(((s >> 26) & 3).astype(np.int32)[hit] - 1, gx[c][hit])
+    assert np.array_equal(((s >> 28) & 3).astype(np.int32)[hit] - 1, gy[c][hit])
+    assert np.array_equal(((s >> 30) & 3).astype(np.int32)[hit] - 1, gz[c][hit])
