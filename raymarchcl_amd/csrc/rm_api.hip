@@ -67,7 +67,7 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf;  // rm_accel.hip structures of the resident volume
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf;  // rm_accel.hip structures of the resident volume
   int accel_iso = -1;                  // isoVal they were built for, -1 = stale
   bool use_accel = true;               // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   std::vector<int> dev_iso;            // isoVal per record, noted by rm_check_device_opts
@@ -167,19 +167,29 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
                     int tile_first, int tile_stride, float* d_tiles, const int* iso_per_pass) {
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), tile_stride);
-  HIP_TRY(hipMemsetAsync(d_tiles, 0, (size_t)tpp * 64 * 16, c->stream));
+  const long long count = (long long)tpp * 64;
+  // passes that share a hit threshold share the derived structures and go out as
+  // one launch (the reference's pipeline always has one isoVal: core.clj:49)
+  HIP_TRY(c->stage_buf.reserve((size_t)iter * count * 16));
+  float* staging = static_cast<float*>(c->stage_buf.p);
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  for (int i = 0; i < iter; i++) {
+  int launches = 0;
+  for (int i0 = 0; i0 < iter;) {
+    int i1 = i0 + 1;
+    while (i1 < iter && iso_per_pass[i1] == iso_per_pass[i0]) i1++;
     rmk::Accel accel;
-    int rc = ensure_accel(c, iso_per_pass[i], &accel);
+    int rc = ensure_accel(c, iso_per_pass[i0], &accel);
     if (rc) return rc;
-    HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, accel, d_mc + (size_t)i * RM_TABLE_FLOATS,
-                                    d_opts + i, resx, d_tiles, n, 0, n, tile_first, tile_stride,
-                                    true, nullptr));
+    HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
+                                       d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4, n,
+                                       tile_first, tile_stride));
+    launches++;
+    i0 = i1;
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(rmk::launch_blend(c->stream, staging, d_opts, iter, count, d_tiles));
   c->timed = true;
-  c->launches = iter;
+  c->launches = launches;
   return RM_OK;
 }
 
@@ -235,7 +245,7 @@ void rm_destroy(rm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf,
+  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf,
                     &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
   for (DevBuf* b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);

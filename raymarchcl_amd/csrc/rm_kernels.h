@@ -8,6 +8,7 @@
 namespace rmk {
 struct Counters;
 
+inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / parts; }
 // number of 8x8 tiles covering work-items 0..n-1 of an image `resx` wide
 int tiles_total(int resx, int n);
 
@@ -19,8 +20,14 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
                               Counters* d_counters);
+// all `iter` passes of a partition in one launch -> staging [iter][tiles_per_part*64] float4
+hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel accel,
+                                 const float* d_mc_all, const RmOpts* d_opts_all, int resx, int iter,
+                                 float* d_staging, int n, int tile_first, int tile_stride);
+// staging -> tile-major accumulators (in-order frame blend)
+hipError_t launch_blend(hipStream_t st, const float* d_staging, const RmOpts* d_opts_all, int iter,
+                        long long count, float* d_tiles);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
-inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / parts; }
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
                           const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,

@@ -86,6 +86,56 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   }
 }
 
+// All passes of a frame in ONE launch: blockIdx.y = pass, blockIdx.x covers the
+// partition's tiles.  Samples of different passes are independent until the
+// blend, so each lane writes its colour*exposure to a staging slot
+// [pass][local tile][lane] and blend_kernel applies the reference's in-order
+// recurrence afterwards.  Compared with one launch per pass this removes the
+// per-pass tail (waves of the next pass fill the CUs while expensive tiles of
+// the previous one finish) and costs the same 32 B per sample the reference
+// spends on its read-modify-write of the accumulator.
+template <bool ACCEL>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void render_samples_kernel(
+    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
+    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
+    const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
+    int tile_stride, int tiles_per_part) {
+  const int pass = blockIdx.y;
+  const RmOpts* __restrict__ opts = opts_all + pass;
+  const int resx = opts->resolution[0];
+  const TileGeom g = tile_geom(resx, n);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long tile = tile_first + slot * tile_stride;
+  if (tile >= g.tiles_total) return;
+  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, 0, n);
+  if (id < 0) return;
+  rmk::Scene sc{vox, mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts, dist8, surf32};
+  rmk::Tracer<false, ACCEL> tr(sc);
+  const rmk::v3 col = tr.shade(id);
+  staging[((long long)pass * tiles_per_part + slot) * 64 + lane] = make_float4(col.x, col.y, col.z, 1.0f);
+}
+
+// In-order accumulation of the staged pass colours: p <- mix(p, c_i, frameBlend_i)
+// for i = 0..iter-1 starting from 0 (renderer.cl:492 applied pass after pass,
+// core.clj:81-90).  Lanes without a pixel hold garbage that nobody reads.
+__global__ __launch_bounds__(256) void blend_kernel(const float4* __restrict__ staging,
+                                                    const RmOpts* __restrict__ opts_all, int iter,
+                                                    long long count, float4* __restrict__ tiles) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long long)gridDim.x * blockDim.x) {
+    float px = 0.f, py = 0.f, pz = 0.f;
+    for (int k = 0; k < iter; k++) {
+      const float fb = opts_all[k].frameBlend;
+      const float4 c = staging[(long long)k * count + i];
+      px = px + (c.x - px) * fb;
+      py = py + (c.y - py) * fb;
+      pz = pz + (c.z - pz) * fb;
+    }
+    tiles[i] = make_float4(px, py, pz, 1.0f);
+  }
+}
+
 __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ pixels,
                                                       const RmOpts* __restrict__ opts,
                                                       uint32_t* __restrict__ argb, int n) {
@@ -188,6 +238,38 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   else if (acc) RM_LAUNCH(false, false, true);
   else RM_LAUNCH(false, false, false);
 #undef RM_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
+                                 const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
+                                 int tile_first, int tile_stride) {
+  const TileGeom g = tile_geom(resx, n);
+  if (tile_stride < 1) tile_stride = 1;
+  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
+  const long long my_tiles =
+      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
+  if (my_tiles == 0 || iter <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((my_tiles + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)iter);
+  const dim3 block(64 * kWavesPerBlock);
+  const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
+  float4* st4 = reinterpret_cast<float4*>(staging);
+  if (accel.dist && accel.surf)
+    render_samples_kernel<true><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all,
+                                                        st4, n, tile_first, tile_stride, tpp);
+  else
+    render_samples_kernel<false><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
+                                                         n, tile_first, tile_stride, tpp);
+  return hipGetLastError();
+}
+
+hipError_t launch_blend(hipStream_t st, const float* staging, const RmOpts* d_opts_all, int iter,
+                        long long count, float* tiles) {
+  if (count <= 0) return hipSuccess;
+  long long blocks = (count + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  blend_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(staging), d_opts_all,
+                                                 iter, count, reinterpret_cast<float4*>(tiles));
   return hipGetLastError();
 }
 

@@ -163,7 +163,7 @@ def test_frame_renderer_single_gpu(gpu_ctx, config2):
     assert _eq(d_px.cpu().numpy(), px)
     assert np.array_equal(d_argb.cpu().numpy().view(np.uint32), argb)
     ms, launches = fr.ctx.last_frame_timing()
-    assert launches == sc["iter"] and ms > 0
+    assert 1 <= launches <= sc["iter"] and ms > 0
     fr.close()
 
 
