@@ -67,10 +67,15 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf;  // rm_accel.hip structures of the resident volume
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf;
+  int wave_mode = 1;    // RAYMARCH_KERNEL=straight -> render_samples_kernel instead of the wave kernel
+  int min_waves = 4;    // RAYMARCH_WAVES=2..5: register budget of the wave kernel
+  int wave_blocks = 0;  // persistent grid size
+  int num_cus = 0;  // rm_accel.hip structures of the resident volume
   int accel_iso = -1;                  // isoVal they were built for, -1 = stale
   bool use_accel = true;               // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   std::vector<int> dev_iso;            // isoVal per record, noted by rm_check_device_opts
+  std::vector<unsigned char> dev_same; // record i == record i-1 except .time
   const void* dev_iso_src = nullptr;
   int rx = 0, ry = 0, rz = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -121,6 +126,18 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   return RM_OK;
 }
 
+// same[i] = 1 when record i equals record i-1 in every byte except .time
+void records_same_as_prev(const void* opts_array, int iter, std::vector<unsigned char>* same) {
+  same->assign(iter, 0);
+  const char* base = static_cast<const char*>(opts_array);
+  const size_t t0 = offsetof(RmOpts, time), t1 = t0 + sizeof(float);
+  for (int i = 1; i < iter; i++) {
+    const char* a = base + (size_t)(i - 1) * RM_OPTS_BYTES;
+    const char* b = base + (size_t)i * RM_OPTS_BYTES;
+    (*same)[i] = memcmp(a, b, t0) == 0 && memcmp(a + t1, b + t1, RM_OPTS_BYTES - t1) == 0;
+  }
+}
+
 int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n, int id0,
                      int id1, rm_counters* counters) {
   int rc = check_ctx(c);
@@ -164,8 +181,12 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   return RM_OK;
 }
 
+// Records i0..i1-1 may share a wave-kernel launch when they are byte-identical
+// apart from .time (what core.clj:99-106 produces).  `uniform[i]` is filled by
+// the callers that have host copies of the records (1 = same as record i-1).
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
-                    int tile_first, int tile_stride, float* d_tiles, const int* iso_per_pass) {
+                    int tile_first, int tile_stride, float* d_tiles, const int* iso_per_pass,
+                    const unsigned char* same_as_prev) {
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), tile_stride);
   const long long count = (long long)tpp * 64;
   // passes that share a hit threshold share the derived structures and go out as
@@ -176,13 +197,24 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
   int launches = 0;
   for (int i0 = 0; i0 < iter;) {
     int i1 = i0 + 1;
-    while (i1 < iter && iso_per_pass[i1] == iso_per_pass[i0]) i1++;
+    const bool wave = c->wave_mode && c->use_accel;
+    while (i1 < iter && iso_per_pass[i1] == iso_per_pass[i0] && (!wave || same_as_prev[i1])) i1++;
     rmk::Accel accel;
     int rc = ensure_accel(c, iso_per_pass[i0], &accel);
     if (rc) return rc;
-    HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
-                                       d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4, n,
-                                       tile_first, tile_stride));
+    if (wave) {
+      HIP_TRY(c->queue_buf.reserve(64));
+      HIP_TRY(rmk::launch_render_wave(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
+                                      d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4, n,
+                                      tile_first, tile_stride,
+                                      static_cast<unsigned int*>(c->queue_buf.p), c->wave_blocks,
+                                      c->min_waves));
+    } else {
+      HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel,
+                                         d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx,
+                                         i1 - i0, staging + (size_t)i0 * count * 4, n, tile_first,
+                                         tile_stride));
+    }
     launches++;
     i0 = i1;
   }
@@ -237,6 +269,14 @@ int rm_create(int device_id, rm_ctx** out) {
   c->stream = c->own_stream;
   const char* na = getenv("RAYMARCH_NO_ACCEL");
   c->use_accel = !(na && na[0] == '1');
+  const char* km = getenv("RAYMARCH_KERNEL");
+  c->wave_mode = !(km && strcmp(km, "straight") == 0);
+  const char* mw = getenv("RAYMARCH_WAVES");
+  if (mw && atoi(mw) >= 2 && atoi(mw) <= 5) c->min_waves = atoi(mw);
+  c->num_cus = prop.multiProcessorCount;
+  c->wave_blocks = c->num_cus * rmk::wave_kernel_blocks_per_cu(c->min_waves);
+  const char* wb = getenv("RAYMARCH_WAVE_BLOCKS");
+  if (wb && atoi(wb) > 0) c->wave_blocks = atoi(wb);
   *out = c;
   return RM_OK;
 }
@@ -245,7 +285,7 @@ void rm_destroy(rm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf,
+  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf, &c->queue_buf,
                     &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
   for (DevBuf* b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -361,12 +401,14 @@ int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, in
   memcpy(&o0, opts_array, sizeof o0);
   const int tiles = rmk::tiles_total(o0.resolution[0], n);
   HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
+  std::vector<unsigned char> same;
+  records_same_as_prev(opts_array, iter, &same);
   std::vector<int> isos(iter);
   for (int i = 0; i < iter; i++)
     isos[i] = static_cast<const uint8_t*>(opts_array)[(size_t)i * RM_OPTS_BYTES + offsetof(RmOpts, isoVal)];
   rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
                        static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
-                       static_cast<float*>(c->tile_buf.p), isos.data());
+                       static_cast<float*>(c->tile_buf.p), isos.data(), same.data());
   if (rc) return rc;
   HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
                               static_cast<const RmOpts*>(c->opts_buf.p),
@@ -390,18 +432,20 @@ int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int wid
   if (rc) return rc;
   if (!d_opts || iter <= 0) return fail(RM_EINVAL, "d_opts NULL or iter = %d", iter);
   if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  std::vector<RmOpts> recs(iter);
+  HIP_TRY(hipMemcpyAsync(recs.data(), d_opts, (size_t)iter * RM_OPTS_BYTES, hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->dev_iso.clear();
+  c->dev_iso_src = nullptr;
   for (int i = 0; i < iter; i++) {
-    RmOpts o;
-    HIP_TRY(hipMemcpyAsync(&o, static_cast<const char*>(d_opts) + (size_t)i * RM_OPTS_BYTES, sizeof o,
-                           hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    rc = check_opts(c, &o, n);
+    rc = check_opts(c, &recs[i], n);
     if (rc) return rc;
-    if (o.resolution[0] != width)
-      return fail(RM_EINVAL, "record %d: resolution.x = %d but width = %d", i, o.resolution[0], width);
-    if (i == 0) c->dev_iso.clear();
-    c->dev_iso.push_back(o.isoVal);
+    if (recs[i].resolution[0] != width)
+      return fail(RM_EINVAL, "record %d: resolution.x = %d but width = %d", i, recs[i].resolution[0], width);
+    c->dev_iso.push_back(recs[i].isoVal);
   }
+  records_same_as_prev(recs.data(), iter, &c->dev_same);
   c->dev_iso_src = d_opts;
   return RM_OK;
 }
@@ -418,7 +462,7 @@ int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, 
   if (c->dev_iso_src != d_opts || (int)c->dev_iso.size() != iter)
     return fail(RM_ESTATE, "rm_check_device_opts(d_opts, iter=%d, ...) must validate the records first", iter);
   return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, tile_first,
-                         tile_stride, d_tiles, c->dev_iso.data());
+                         tile_stride, d_tiles, c->dev_iso.data(), c->dev_same.data());
 }
 
 int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void* d_opts, int n,

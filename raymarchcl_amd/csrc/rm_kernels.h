@@ -24,6 +24,13 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel accel,
                                  const float* d_mc_all, const RmOpts* d_opts_all, int resx, int iter,
                                  float* d_staging, int n, int tile_first, int tile_stride);
+// the same, by the persistent wave-scheduled kernel (needs the accel structures and
+// option records that differ only in .time); d_queue: one device uint32 of scratch
+hipError_t launch_render_wave(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,
+                              const RmOpts* d_opts_all, int resx, int iter, float* d_staging, int n,
+                              int tile_first, int tile_stride, unsigned int* d_queue, int blocks,
+                              int min_waves);
+int wave_kernel_blocks_per_cu(int min_waves);
 // staging -> tile-major accumulators (in-order frame blend)
 hipError_t launch_blend(hipStream_t st, const float* d_staging, const RmOpts* d_opts_all, int iter,
                         long long count, float* d_tiles);

@@ -17,6 +17,7 @@
 
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
+#include "rm_wave.hpp"
 
 namespace {
 
@@ -114,6 +115,71 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_samples_kernel(
   rmk::Tracer<false, ACCEL> tr(sc);
   const rmk::v3 col = tr.shade(id);
   staging[((long long)pass * tiles_per_part + slot) * 64 + lane] = make_float4(col.x, col.y, col.z, 1.0f);
+}
+
+// Persistent, wave-scheduled renderer (rm_wave.hpp): each wavefront pulls tiles
+// from a queue, keeps a pool of (pixel, pass) samples of its tile, and
+// alternates between one shared march loop and short per-lane continuations.
+constexpr int kWaitLanes = 12;   // run continuations once this many lanes wait for one
+constexpr int kMarchBudget = 2;  // lookups per lane between two ballots
+
+// MINW = waves per SIMD the register allocator must leave room for (2: no spills,
+// ~200 VGPRs; 4: 128 VGPRs with the cold lane state spilled to scratch).
+template <int MINW>
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_wave_kernel(rmk::WaveArgs a) {
+  rmk::WaveTracer T(a);
+  rmk::WaveLane L{};
+  L.st = rmk::S_IDLE;
+  L.marching = false;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int pool = 64 * a.iter;
+  const TileGeom g = tile_geom(a.resx, a.n);
+  int slot = 0, next = pool;  // wave-uniform: current local tile, next sample of its pool
+  bool exhausted = false;
+  for (;;) {
+    // ---- hand samples to idle lanes
+    unsigned long long need = __ballot(L.st == rmk::S_IDLE);
+    while (need != 0ull && !exhausted) {
+      if (next >= pool) {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(a.queue, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= (unsigned int)a.my_tiles) { exhausted = true; break; }
+        slot = (int)t;
+        next = 0;
+      }
+      if (L.st == rmk::S_IDLE) {
+        const int s = next + __popcll(need & below);
+        if (s < pool) {
+          const int pass = s >> 6, pix = s & 63;
+          const long long tile = a.tile_first + (long long)slot * a.tile_stride;
+          const int id = lane_pixel((int)tile, pix, a.resx, g.tiles_x, a.n, 0, a.n);
+          if (id >= 0) {
+            L.id = id;
+            L.pass = pass;
+            L.out_idx = (pass * a.tiles_per_part + slot) * 64 + pix;
+            L.st = rmk::S_NEW;
+          }
+        }
+      }
+      next = min(pool, next + __popcll(need));
+      need = __ballot(L.st == rmk::S_IDLE);
+    }
+    // ---- continuations: afterwards every lane is marching or idle
+    if (!L.marching && L.st != rmk::S_IDLE) T.advance(L);
+    unsigned long long m = __ballot(L.marching);
+    if (m == 0ull) {
+      if (exhausted && __ballot(L.st != rmk::S_IDLE) == 0ull) break;
+      continue;
+    }
+    // ---- the shared march loop
+    const int m0 = __popcll(m);
+    do {
+      if (L.marching) T.march_some(L, kMarchBudget);
+      m = __ballot(L.marching);
+    } while (m != 0ull && m0 - __popcll(m) < kWaitLanes);
+  }
 }
 
 // In-order accumulation of the staged pass colours: p <- mix(p, c_i, frameBlend_i)
@@ -261,6 +327,56 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
     render_samples_kernel<false><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
                                                          n, tile_first, tile_stride, tpp);
   return hipGetLastError();
+}
+
+hipError_t launch_render_wave(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
+                              const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
+                              int tile_first, int tile_stride, unsigned int* d_queue, int blocks,
+                              int min_waves) {
+  const TileGeom g = tile_geom(resx, n);
+  if (tile_stride < 1) tile_stride = 1;
+  WaveArgs a;
+  a.vox = vox;
+  a.dist8 = accel.dist;
+  a.surf32 = accel.surf;
+  a.mc_all = reinterpret_cast<const float4*>(mc_all);
+  a.opts_all = d_opts_all;
+  a.staging = reinterpret_cast<float4*>(staging);
+  a.queue = d_queue;
+  a.n = n;
+  a.iter = iter;
+  a.tile_first = tile_first;
+  a.tile_stride = tile_stride;
+  a.tiles_per_part = tiles_per_part(g.tiles_total, tile_stride);
+  a.my_tiles = tile_first >= g.tiles_total
+                   ? 0
+                   : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
+  a.resx = resx;
+  if (a.my_tiles == 0 || iter <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  const int waves_needed = (a.my_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > waves_needed) blocks = waves_needed;
+  switch (min_waves) {
+    case 2: render_wave_kernel<2><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
+    case 3: render_wave_kernel<3><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
+    case 5: render_wave_kernel<5><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
+    default: render_wave_kernel<4><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
+  }
+  return hipGetLastError();
+}
+
+int wave_kernel_blocks_per_cu(int min_waves) {
+  int nb = 0;
+  hipError_t e;
+  switch (min_waves) {
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<2>, 64 * kWavesPerBlock, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<3>, 64 * kWavesPerBlock, 0); break;
+    case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<5>, 64 * kWavesPerBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<4>, 64 * kWavesPerBlock, 0); break;
+  }
+  if (e != hipSuccess || nb < 1) nb = 1;
+  return nb;
 }
 
 hipError_t launch_blend(hipStream_t st, const float* staging, const RmOpts* d_opts_all, int iter,

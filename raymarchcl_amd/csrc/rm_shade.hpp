@@ -83,6 +83,77 @@ RM_DEV bool advance_exact(v3& p, v3 delta, int k) {
   return ok;
 }
 
+// ---- leaf routines shared by the straight (Tracer) and wave-scheduled
+// (rm_wave.hpp) forms; `o` points at the option record in device memory ----
+
+// materials[id] by byte offset, defined for every id (see oracle/rm_restate.c);
+// *oob is set when the index falls outside the record (undefined in the reference)
+RM_DEV Material material_of(const RmOpts& o, int id, bool* oob = nullptr) {
+  Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
+  const int off = (int)offsetof(RmOpts, materials) + (int)sizeof(RmMaterial) * id;
+  if (id < -13 || id > 3) {
+    if (oob) *oob = true;
+    return m;
+  }
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(&o) + off);
+  m.albedo = V(p[0], p[1], p[2]);
+  m.r0 = p[4];
+  m.smoothness = p[5];
+  return m;
+}
+// slab test: renderer.cl:153-161
+RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
+  const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
+              loz = (o.voxelBoundsMin[2] - p.z) / d.z;
+  const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
+              hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
+  const float nx = rmd::fmin_cl(hix, lox), ny = rmd::fmin_cl(hiy, loy), nz = rmd::fmin_cl(hiz, loz);
+  const float a = rmd::fmax_cl(rmd::fmax_cl(nx, 0.0f), rmd::fmax_cl(ny, nz));
+  const float fx = rmd::fmax_cl(hix, lox), fy = rmd::fmax_cl(hiy, loy), fz = rmd::fmax_cl(hiz, loz);
+  const float b = rmd::fmin_cl(fx, rmd::fmin_cl(fy, fz));
+  return b > a ? a : -1.0f;
+}
+RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {
+  return qz >= 0 && qz < o.voxelRes[2] && qy >= 0 && qy < o.voxelRes[1] && qx >= 0 &&
+         qx < o.voxelRes[0];
+}
+// renderer.cl:259-261
+RM_DEV v3 sky_of(const RmOpts& o, v3 dir) {
+  return mixs(ld3(o.skyColor1), ld3(o.skyColor2), dir.y * 0.5f + 0.5f);
+}
+// renderer.cl:271-273
+RM_DEV v3 reflect_of(v3 v, v3 n) {
+  const float k = 2.0f * dot(v, n);
+  return v - n * k;
+}
+// renderer.cl:304-311
+RM_DEV float schlick_of(float r0, float smooth, v3 n, v3 view) {
+  const float d = rmd::clamp_cl(1.0f - dot(n, -view), 0.0f, 1.0f);
+  if (d > 0.0f) {
+    const float d2 = d * d;
+    return (1.0f - r0) * (smooth * d2 * d2 * d) + r0;
+  }
+  return 0.0f;
+}
+// renderer.cl:317-325
+RM_DEV float blinn_phong_of(float smooth, v3 raydir, v3 ldir, v3 n) {
+  const float nh = dot(normalize(ldir - raydir), n);
+  if (nh > 0.0f) {
+    const float sp = rmd::exp2_det(6.0f * smooth + 4.0f);
+    return rmd::pow_det(nh, sp) * (sp + 2.0f) * 0.125f;
+  }
+  return 0.0f;
+}
+// decode of a surf32 word (rm_accel.hip) into the hit normal and material code
+RM_DEV v3 surf_normal(uint32_t w, bool smooth) {
+  if (smooth)
+    return normalize(V((float)((int)((w >> 8) & 63u) - 32), (float)((int)((w >> 14) & 63u) - 32),
+                       (float)((int)((w >> 20) & 63u) - 32)));
+  return normalize(V(-(float)((int)((w >> 26) & 3u) - 1), -(float)((int)((w >> 28) & 3u) - 1),
+                     -(float)((int)((w >> 30) & 3u) - 1)));
+}
+RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }  // renderer.cl:205-207
+
 template <bool COUNT, bool ACCEL = false>
 struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
@@ -96,40 +167,15 @@ struct Tracer {
     return sc.mc[seed & (RM_TABLE_ENTRIES - 1)];
   }
 
-  // materials[id] by byte offset, defined for every id (see oracle/rm_restate.c)
   RM_DEV Material material(int id) {
-    Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
-    const int off = (int)offsetof(RmOpts, materials) + (int)sizeof(RmMaterial) * id;
-    if (id < -13 || id > 3) {
-      if (COUNT) cnt.oob_material++;
-      return m;
-    }
-    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sc.o) + off);
-    m.albedo = V(p[0], p[1], p[2]);
-    m.r0 = p[4];
-    m.smoothness = p[5];
+    bool oob = false;
+    const Material m = material_of(*sc.o, id, &oob);
+    if (COUNT && oob) cnt.oob_material++;
     return m;
   }
+  RM_DEV float box_entry(v3 p, v3 d) { return box_entry_of(*sc.o, p, d); }
 
-  // slab test: renderer.cl:153-161
-  RM_DEV float box_entry(v3 p, v3 d) {
-    const RmOpts& o = *sc.o;
-    const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
-                loz = (o.voxelBoundsMin[2] - p.z) / d.z;
-    const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
-                hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
-    const float nx = rmd::fmin_cl(hix, lox), ny = rmd::fmin_cl(hiy, loy), nz = rmd::fmin_cl(hiz, loz);
-    const float a = rmd::fmax_cl(rmd::fmax_cl(nx, 0.0f), rmd::fmax_cl(ny, nz));
-    const float fx = rmd::fmax_cl(hix, lox), fy = rmd::fmax_cl(hiy, loy), fz = rmd::fmax_cl(hiz, loz);
-    const float b = rmd::fmin_cl(fx, rmd::fmin_cl(fy, fz));
-    return b > a ? a : -1.0f;
-  }
-
-  RM_DEV bool in_grid(int qx, int qy, int qz) {
-    const RmOpts& o = *sc.o;
-    return qz >= 0 && qz < o.voxelRes[2] && qy >= 0 && qy < o.voxelRes[1] && qx >= 0 &&
-           qx < o.voxelRes[0];
-  }
+  RM_DEV bool in_grid(int qx, int qy, int qz) { return in_grid_of(*sc.o, qx, qy, qz); }
   // binary occupancy: renderer.cl:172-178
   RM_DEV float solid(int qx, int qy, int qz) {
     const RmOpts& o = *sc.o;
@@ -190,13 +236,7 @@ struct Tracer {
           if (dcell == 0) {
             const uint32_t w = sc.surf[cell];
             const int v = (int)(w & 0xffu);
-            if (smooth) {
-              nrm = normalize(V((float)((int)((w >> 8) & 63u) - 32), (float)((int)((w >> 14) & 63u) - 32),
-                                (float)((int)((w >> 20) & 63u) - 32)));
-            } else {
-              nrm = normalize(V(-(float)((int)((w >> 26) & 3u) - 1), -(float)((int)((w >> 28) & 3u) - 1),
-                                -(float)((int)((w >> 30) & 3u) - 1)));
-            }
+            nrm = surf_normal(w, smooth);
             const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
             const float d = length(rpos - hit) - o.voxelSize;
             if (d < rd) { rd = d; rc = v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }
@@ -258,11 +298,7 @@ struct Tracer {
     }
   }
 
-  // renderer.cl:259-261
-  RM_DEV v3 sky(v3 dir) {
-    const RmOpts& o = *sc.o;
-    return mixs(ld3(o.skyColor1), ld3(o.skyColor2), dir.y * 0.5f + 0.5f);
-  }
+  RM_DEV v3 sky(v3 dir) { return sky_of(*sc.o, dir); }
 
   struct Sample { v3 eye; v3 mcNormal; float px, py; float time; };
 
@@ -273,11 +309,7 @@ struct Tracer {
     const float4 r = table(seed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
-  // renderer.cl:271-273
-  RM_DEV v3 reflect(v3 v, v3 n) {
-    const float k = 2.0f * dot(v, n);
-    return v - n * k;
-  }
+  RM_DEV v3 reflect(v3 v, v3 n) { return reflect_of(v, n); }
   // fog + flares: renderer.cl:275-290
   RM_DEV v3 atmosphere(const Sample& s, v3 ro, v3 rdir, float dist, v3 col) {
     const RmOpts& o = *sc.o;
@@ -300,23 +332,9 @@ struct Tracer {
     march(p, ldir, h, lmax, sc.o->shadowIter, false);
     return rmd::step_cl(lmax, h.distance);
   }
-  // renderer.cl:304-311
-  RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) {
-    const float d = rmd::clamp_cl(1.0f - dot(n, -view), 0.0f, 1.0f);
-    if (d > 0.0f) {
-      const float d2 = d * d;
-      return (1.0f - r0) * (smooth * d2 * d2 * d) + r0;
-    }
-    return 0.0f;
-  }
-  // renderer.cl:317-325
+  RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) { return schlick_of(r0, smooth, n, view); }
   RM_DEV float blinn_phong(float smooth, v3 raydir, v3 ldir, v3 n) {
-    const float nh = dot(normalize(ldir - raydir), n);
-    if (nh > 0.0f) {
-      const float sp = rmd::exp2_det(6.0f * smooth + 4.0f);
-      return rmd::pow_det(nh, sp) * (sp + 2.0f) * 0.125f;
-    }
-    return 0.0f;
+    return blinn_phong_of(smooth, raydir, ldir, n);
   }
   // renderer.cl:327-346
   RM_DEV float occlusion(const Sample& s, v3 pos, v3 normal) {

@@ -176,3 +176,26 @@ def _runs(ids):
             lo = v
         prev = v
     yield lo, prev + 1
+
+
+def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, monkeypatch):
+    """Records that differ in more than .time cannot share a wave-kernel launch:
+    the host splits them into runs.  Every kernel variant must agree with the oracle."""
+    sc = scenes.build("metal_3spp")
+    n = sc["n"]
+    opts = bytearray(sc["opts"])
+    opts[544 + 260:544 + 264] = np.float32(2.0).tobytes()        # pass 1: other exposure
+    opts[2 * 544 + 284] = 100                                   # pass 2: other isoVal
+    opts = bytes(opts)
+    want, want_argb = oracle_mod.render_frame(sc["vox"], opts, sc["mc"], n)
+    for env in ({}, {"RAYMARCH_WAVES": "2"}, {"RAYMARCH_WAVES": "5"}, {"RAYMARCH_KERNEL": "straight"},
+                {"RAYMARCH_NO_ACCEL": "1"}, {"RAYMARCH_WAVE_BLOCKS": "3"}):
+        for k in ("RAYMARCH_WAVES", "RAYMARCH_KERNEL", "RAYMARCH_NO_ACCEL", "RAYMARCH_WAVE_BLOCKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with native.Context(0) as ctx:
+            ctx.set_volume(sc["vox"], sc["vres"])
+            px, argb = ctx.render_frame(opts, sc["mc"], n)
+        assert _eq(px, want), (env, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
+        assert np.array_equal(argb, want_argb), env
