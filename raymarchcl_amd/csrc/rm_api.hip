@@ -68,9 +68,10 @@ struct rm_ctx {
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
   DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf;
-  int wave_mode = 1;    // RAYMARCH_KERNEL=straight -> render_samples_kernel instead of the wave kernel
+  int wave_mode = 0;    // RAYMARCH_KERNEL=wave -> persistent wave-scheduled kernel (experimental)
   int min_waves = 4;    // RAYMARCH_WAVES=2..5: register budget of the wave kernel
   int wave_blocks = 0;  // persistent grid size
+  int wait_lanes = 16;  // RAYMARCH_WAIT_LANES: continuation/march vote weight in 1/16 (16 = plain majority)
   int num_cus = 0;  // rm_accel.hip structures of the resident volume
   int accel_iso = -1;                  // isoVal they were built for, -1 = stale
   bool use_accel = true;               // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
@@ -208,7 +209,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
                                       d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4, n,
                                       tile_first, tile_stride,
                                       static_cast<unsigned int*>(c->queue_buf.p), c->wave_blocks,
-                                      c->min_waves));
+                                      c->min_waves, c->wait_lanes));
     } else {
       HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel,
                                          d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx,
@@ -270,11 +271,13 @@ int rm_create(int device_id, rm_ctx** out) {
   const char* na = getenv("RAYMARCH_NO_ACCEL");
   c->use_accel = !(na && na[0] == '1');
   const char* km = getenv("RAYMARCH_KERNEL");
-  c->wave_mode = !(km && strcmp(km, "straight") == 0);
+  c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
   const char* mw = getenv("RAYMARCH_WAVES");
   if (mw && atoi(mw) >= 2 && atoi(mw) <= 5) c->min_waves = atoi(mw);
   c->num_cus = prop.multiProcessorCount;
   c->wave_blocks = c->num_cus * rmk::wave_kernel_blocks_per_cu(c->min_waves);
+  const char* wl = getenv("RAYMARCH_WAIT_LANES");
+  if (wl && atoi(wl) > 0) c->wait_lanes = atoi(wl);
   const char* wb = getenv("RAYMARCH_WAVE_BLOCKS");
   if (wb && atoi(wb) > 0) c->wave_blocks = atoi(wb);
   *out = c;

@@ -29,7 +29,7 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel acc
 hipError_t launch_render_wave(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,
                               const RmOpts* d_opts_all, int resx, int iter, float* d_staging, int n,
                               int tile_first, int tile_stride, unsigned int* d_queue, int blocks,
-                              int min_waves);
+                              int min_waves, int wait_lanes);
 int wave_kernel_blocks_per_cu(int min_waves);
 // staging -> tile-major accumulators (in-order frame blend)
 hipError_t launch_blend(hipStream_t st, const float* d_staging, const RmOpts* d_opts_all, int iter,

@@ -120,7 +120,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_samples_kernel(
 // Persistent, wave-scheduled renderer (rm_wave.hpp): each wavefront pulls tiles
 // from a queue, keeps a pool of (pixel, pass) samples of its tile, and
 // alternates between one shared march loop and short per-lane continuations.
-constexpr int kWaitLanes = 12;   // run continuations once this many lanes wait for one
 constexpr int kMarchBudget = 2;  // lookups per lane between two ballots
 
 // MINW = waves per SIMD the register allocator must leave room for (2: no spills,
@@ -166,19 +165,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_wave_kernel(
       next = min(pool, next + __popcll(need));
       need = __ballot(L.st == rmk::S_IDLE);
     }
-    // ---- continuations: afterwards every lane is marching or idle
-    if (!L.marching && L.st != rmk::S_IDLE) T.advance(L);
-    unsigned long long m = __ballot(L.marching);
-    if (m == 0ull) {
-      if (exhausted && __ballot(L.st != rmk::S_IDLE) == 0ull) break;
+    // ---- vote: run whichever phase has more lanes ready for it
+    const bool wants_step = !L.marching && L.st != rmk::S_IDLE;
+    const unsigned long long mc = __ballot(wants_step);
+    const unsigned long long mm = __ballot(L.marching);
+    if ((mc | mm) == 0ull) {
+      if (exhausted) break;
       continue;
     }
-    // ---- the shared march loop
-    const int m0 = __popcll(m);
-    do {
-      if (L.marching) T.march_some(L, kMarchBudget);
-      m = __ballot(L.marching);
-    } while (m != 0ull && m0 - __popcll(m) < kWaitLanes);
+    if (__popcll(mc) * a.wait_lanes >= __popcll(mm) * 16) {
+      if (wants_step) T.advance(L);  // one continuation step
+    } else {
+      if (L.marching) T.march_some(L, kMarchBudget);  // the shared march loop
+    }
   }
 }
 
@@ -332,7 +331,7 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
 hipError_t launch_render_wave(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
                               const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
                               int tile_first, int tile_stride, unsigned int* d_queue, int blocks,
-                              int min_waves) {
+                              int min_waves, int wait_lanes) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   WaveArgs a;
@@ -352,6 +351,7 @@ hipError_t launch_render_wave(hipStream_t st, const uint8_t* vox, Accel accel, c
                    ? 0
                    : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
   a.resx = resx;
+  a.wait_lanes = wait_lanes;
   if (a.my_tiles == 0 || iter <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned int), st);
   if (e != hipSuccess) return e;

@@ -37,6 +37,7 @@ struct WaveArgs {
   float4* __restrict__ staging;          // [iter][tiles_per_part*64]
   unsigned int* __restrict__ queue;      // next local tile to hand out
   int n, iter, tile_first, tile_stride, tiles_per_part, my_tiles, resx;
+  int wait_lanes;  // scheduling vote weight of continuation lanes, in 1/16
 };
 
 enum : int {
@@ -238,9 +239,9 @@ struct WaveTracer {
     L.st = S_IDLE;
   }
 
-  // Run the lane's continuation until it has a march to do or no sample left.
+  // One continuation step of a lane that is neither marching nor idle.
   RM_DEV void advance(WaveLane& L) {
-    while (!L.marching && L.st != S_IDLE) {
+    {
       switch (L.st) {
         case S_NEW: {  // renderer.cl:467-476, :456-465
           const float t = a.opts_all[L.pass].time;
@@ -263,27 +264,37 @@ struct WaveTracer {
           start_ray(L, K_PRIMARY, L.rd0, o.maxDist, o.maxIter);
           break;
         }
-        case S_RAY_RES: {  // renderer.cl:246-250
-          L.obj = rmd::f2i(L.res_c);
-          if (__builtin_fabsf(L.res_d) <= o.eps || L.dist >= L.maxDist) { ray_done(L); break; }
-          L.dist += L.res_d;
-          L.st = S_RAY_STEP;
-          break;
-        }
+        case S_RAY_RES:     // renderer.cl:246-250: a marched estimate came back
         case S_RAY_STEP: {  // renderer.cl:243-245
-          if (--L.osteps < 0) { ray_done(L); break; }
+          // The outer march stays in this tight loop while its estimates need no
+          // fixed-step walk (ray outside the voxel box / ground closer): those are
+          // the majority of estimates and cost one slab test each.
           const v3 rd = ray_dir(L);
-          const v3 pos = mads(rd, L.dist, ray_org(L));
-          begin_estimate(L, pos, rd, o.maxVoxelIter, L.rk == K_PRIMARY, S_RAY_RES);
+          const v3 ro = ray_org(L);
+          bool have = L.st == S_RAY_RES;
+          bool finished = false;
+          for (int guard = 0; guard < 24; guard++) {
+            if (have) {
+              L.obj = rmd::f2i(L.res_c);
+              if (__builtin_fabsf(L.res_d) <= o.eps || L.dist >= L.maxDist) { finished = true; break; }
+              L.dist += L.res_d;
+            }
+            if (--L.osteps < 0) { finished = true; break; }
+            begin_estimate(L, mads(rd, L.dist, ro), rd, o.maxVoxelIter, L.rk == K_PRIMARY, S_RAY_RES);
+            if (L.marching) break;
+            have = true;
+          }
+          if (finished) ray_done(L);
+          // (guard exhausted: st == S_RAY_RES with the last result pending, resumes next step)
           break;
         }
-        case S_AO_RES: {  // renderer.cl:343
-          L.ao *= 1.0f - rmd::fmax_cl((L.ao_d - L.res_d) * o.aoAmp / L.ao_d, 0.0f);
-          L.ao_i++;
-          L.st = S_AO_STEP;
-          break;
-        }
+        case S_AO_RES:     // renderer.cl:343: a probe came back
         case S_AO_STEP: {  // renderer.cl:338-342
+          if (L.st == S_AO_RES) {
+            L.ao *= 1.0f - rmd::fmax_cl((L.ao_d - L.res_d) * o.aoAmp / L.ao_d, 0.0f);
+            L.ao_i++;
+            L.st = S_AO_STEP;
+          }
           if (L.ao_i <= o.aoIter && (double)L.ao > 0.01) {
             L.ao_d += o.aoStepDist;
             L.ao_seed += 37u;
