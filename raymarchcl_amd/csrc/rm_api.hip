@@ -16,6 +16,7 @@
 #include "../../include/raymarch_hip.h"
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
+#include "rm_stream.h"
 
 static_assert(sizeof(rm_counters) == sizeof(rmk::Counters), "counter structs must match");
 static_assert(RM_OPTS_BYTES == RM_OPTS_SIZE, "option record size");
@@ -67,7 +68,9 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf;
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf;
+  int stream_mode = 1;                 // RAYMARCH_KERNEL=stream (default) | straight | wave
+  long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
   int wave_mode = 0;    // RAYMARCH_KERNEL=wave -> persistent wave-scheduled kernel (experimental)
   int min_waves = 4;    // RAYMARCH_WAVES=2..5: register budget of the wave kernel
   int wave_blocks = 0;  // persistent grid size
@@ -77,6 +80,7 @@ struct rm_ctx {
   bool use_accel = true;               // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   std::vector<int> dev_iso;            // isoVal per record, noted by rm_check_device_opts
   std::vector<unsigned char> dev_same; // record i == record i-1 except .time
+  std::vector<RmOpts> dev_recs;        // host copy of the checked records
   const void* dev_iso_src = nullptr;
   int rx = 0, ry = 0, rz = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -187,7 +191,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
 // the callers that have host copies of the records (1 = same as record i-1).
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
                     int tile_first, int tile_stride, float* d_tiles, const int* iso_per_pass,
-                    const unsigned char* same_as_prev) {
+                    const unsigned char* same_as_prev, const RmOpts* host_recs) {
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), tile_stride);
   const long long count = (long long)tpp * 64;
   // passes that share a hit threshold share the derived structures and go out as
@@ -203,6 +207,43 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     rmk::Accel accel;
     int rc = ensure_accel(c, iso_per_pass[i0], &accel);
     if (rc) return rc;
+    const RmOpts& h0 = host_recs[i0];
+    const bool stream = c->stream_mode && c->use_accel && h0.aoIter >= 0 &&
+                        h0.aoIter <= rmk::kStreamMaxAoIter && h0.reflectIter <= rmk::kStreamMaxReflect;
+    if (stream) {
+      // split the run further so that records differ only in .time, then into batches
+      int j0 = i0;
+      while (j0 < i1) {
+        int j1 = j0 + 1;
+        while (j1 < i1 && same_as_prev[j1]) j1++;
+        const int levels = 1 + (host_recs[j0].reflectIter > 0 ? host_recs[j0].reflectIter : 0);
+        const int nl = host_recs[j0].numLights;
+        long long per = c->batch_samples / count;
+        if (per < 1) per = 1;
+        for (int b0 = j0; b0 < j1;) {
+          int b1 = (int)((long long)b0 + per < j1 ? b0 + per : j1);
+          while ((long long)(b1 - b0) * count > rmk::kStreamMaxSamples && b1 > b0 + 1) b1--;
+          rmk::StreamLaunch sl;
+          sl.vox = c->d_vox;
+          sl.accel = accel;
+          sl.mc = d_mc + (size_t)b0 * RM_TABLE_FLOATS;
+          sl.opts = d_opts + b0;
+          sl.staging = staging + (size_t)b0 * count * 4;
+          sl.n = n; sl.resx = resx; sl.passes = b1 - b0; sl.count = (int)count;
+          sl.tile_first = tile_first; sl.tile_stride = tile_stride;
+          sl.levels = levels; sl.num_lights = nl < 1 ? 1 : nl;
+          sl.queue_blocks = c->num_cus * 8;
+          HIP_TRY(c->work_buf.reserve(rmk::stream_workspace_bytes(sl.passes * sl.count, levels, sl.num_lights)));
+          sl.workspace = c->work_buf.p;
+          HIP_TRY(rmk::launch_stream_batch(c->stream, sl));
+          launches++;
+          b0 = b1;
+        }
+        j0 = j1;
+      }
+      i0 = i1;
+      continue;
+    }
     if (wave) {
       HIP_TRY(c->queue_buf.reserve(64));
       HIP_TRY(rmk::launch_render_wave(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
@@ -272,6 +313,9 @@ int rm_create(int device_id, rm_ctx** out) {
   c->use_accel = !(na && na[0] == '1');
   const char* km = getenv("RAYMARCH_KERNEL");
   c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
+  c->stream_mode = !km || strcmp(km, "stream") == 0;
+  const char* bs = getenv("RAYMARCH_BATCH_SAMPLES");
+  if (bs && atoll(bs) > 0) c->batch_samples = atoll(bs);
   const char* mw = getenv("RAYMARCH_WAVES");
   if (mw && atoi(mw) >= 2 && atoi(mw) <= 5) c->min_waves = atoi(mw);
   c->num_cus = prop.multiProcessorCount;
@@ -288,7 +332,7 @@ void rm_destroy(rm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf, &c->queue_buf,
+  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf, &c->queue_buf, &c->work_buf,
                     &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
   for (DevBuf* b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -406,12 +450,14 @@ int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, in
   HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
   std::vector<unsigned char> same;
   records_same_as_prev(opts_array, iter, &same);
+  std::vector<RmOpts> recs(iter);
+  memcpy(recs.data(), opts_array, (size_t)iter * RM_OPTS_BYTES);
   std::vector<int> isos(iter);
   for (int i = 0; i < iter; i++)
     isos[i] = static_cast<const uint8_t*>(opts_array)[(size_t)i * RM_OPTS_BYTES + offsetof(RmOpts, isoVal)];
   rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
                        static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
-                       static_cast<float*>(c->tile_buf.p), isos.data(), same.data());
+                       static_cast<float*>(c->tile_buf.p), isos.data(), same.data(), recs.data());
   if (rc) return rc;
   HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
                               static_cast<const RmOpts*>(c->opts_buf.p),
@@ -449,6 +495,7 @@ int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int wid
     c->dev_iso.push_back(recs[i].isoVal);
   }
   records_same_as_prev(recs.data(), iter, &c->dev_same);
+  c->dev_recs = recs;
   c->dev_iso_src = d_opts;
   return RM_OK;
 }
@@ -465,7 +512,8 @@ int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, 
   if (c->dev_iso_src != d_opts || (int)c->dev_iso.size() != iter)
     return fail(RM_ESTATE, "rm_check_device_opts(d_opts, iter=%d, ...) must validate the records first", iter);
   return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, tile_first,
-                         tile_stride, d_tiles, c->dev_iso.data(), c->dev_same.data());
+                         tile_stride, d_tiles, c->dev_iso.data(), c->dev_same.data(),
+                         c->dev_recs.data());
 }
 
 int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void* d_opts, int n,

@@ -188,7 +188,8 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
     opts[2 * 544 + 284] = 100                                   # pass 2: other isoVal
     opts = bytes(opts)
     want, want_argb = oracle_mod.render_frame(sc["vox"], opts, sc["mc"], n)
-    for env in ({}, {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "2"},
+    for env in ({}, {"RAYMARCH_KERNEL": "stream", "RAYMARCH_BATCH_SAMPLES": "4000"},
+                {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "2"},
                 {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "4"}, {"RAYMARCH_KERNEL": "straight"},
                 {"RAYMARCH_NO_ACCEL": "1"}, {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVE_BLOCKS": "3"}):
         for k in ("RAYMARCH_WAVES", "RAYMARCH_KERNEL", "RAYMARCH_NO_ACCEL", "RAYMARCH_WAVE_BLOCKS"):
