@@ -159,6 +159,13 @@ struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
   const Scene& sc;
   Counters cnt;  // per-lane, only touched when COUNT
+#ifdef RM_WORK_STATS
+  // debug build only: what the accelerated path actually executes
+  unsigned int ws_iters = 0, ws_filtered = 0, ws_walks = 0, ws_lookups = 0, ws_jumps = 0;
+#define RM_WS(x) (x)
+#else
+#define RM_WS(x) ((void)0)
+#endif
   RM_DEV explicit Tracer(const Scene& s) : sc(s), cnt{} {}
 
   // scatter table lookup: renderer.cl:142-144
@@ -226,6 +233,7 @@ struct Tracer {
         const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
                               __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
+        RM_WS(ws_walks++);
         while (steps > 0) {
           const int qx = rmd::convert_int_sat(p.x * frx);
           const int qy = rmd::convert_int_sat(p.y * fry);
@@ -233,6 +241,7 @@ struct Tracer {
           if (!in_grid(qx, qy, qz)) break;
           const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
           const int dcell = sc.dist[cell];
+          RM_WS(ws_lookups++);
           if (dcell == 0) {
             const uint32_t w = sc.surf[cell];
             const int v = (int)(w & 0xffu);
@@ -246,9 +255,9 @@ struct Tracer {
           int j = (int)((float)(dcell - 2) * inv_s);
           if (j >= 4 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
             if (j >= steps) break;  // the walk ends before it can reach anything
-            if (advance_exact(p, delta, j)) { steps -= j; continue; }
+            if (advance_exact(p, delta, j)) { steps -= j; RM_WS(ws_jumps++); continue; }
             j = j >> 2;
-            if (j >= 4 && advance_exact(p, delta, j)) { steps -= j; continue; }
+            if (j >= 4 && advance_exact(p, delta, j)) { steps -= j; RM_WS(ws_jumps++); continue; }
           }
           p = p + delta;
           steps -= 1;
@@ -279,14 +288,68 @@ struct Tracer {
   struct Hit { v3 pos, normal; float distance; int objectID; };
 
   // outer march: renderer.cl:239-257
+  //
+  // Most distance estimates of a ray never reach the voxel walk: the ray is past
+  // the clip box, misses it, or the ground is closer than the box entry -- yet
+  // the reference pays a slab test (6 IEEE divisions) for each of them.  For a
+  // ray ro + t*rd the entry/exit parameters at distance t are (lo - t, hi - t)
+  // with lo/hi evaluated ONCE at t = 0, so an approximate copy of them decides
+  // the test whenever the outcome is not within `slack` of flipping; only the
+  // ambiguous estimates (and those that do walk) run the exact code.  The
+  // outcome of every skipped test is certain, so results do not change.
+  struct BoxFilter {
+    float near0, far0, slack;
+    bool ok;
+  };
+  RM_DEV BoxFilter make_filter(v3 ro, v3 rd) {
+    const RmOpts& o = *sc.o;
+    BoxFilter f;
+    const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
+    // tiny components make the parameters huge (and 0 makes them inf/NaN): no filter
+    f.ok = fminf(fminf(ax, ay), az) >= 1e-3f && fmaxf(fmaxf(ax, ay), az) <= 2.0f &&
+           fmaxf(fmaxf(__builtin_fabsf(ro.x), __builtin_fabsf(ro.y)), __builtin_fabsf(ro.z)) <= 64.0f;
+    const float ix = __builtin_amdgcn_rcpf(rd.x), iy = __builtin_amdgcn_rcpf(rd.y),
+                iz = __builtin_amdgcn_rcpf(rd.z);
+    const float lx = (o.voxelBoundsMin[0] - ro.x) * ix, hx = (o.voxelBoundsMax[0] - ro.x) * ix;
+    const float ly = (o.voxelBoundsMin[1] - ro.y) * iy, hy = (o.voxelBoundsMax[1] - ro.y) * iy;
+    const float lz = (o.voxelBoundsMin[2] - ro.z) * iz, hz = (o.voxelBoundsMax[2] - ro.z) * iz;
+    f.near0 = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz));
+    f.far0 = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz));
+    // positions are rounded to ~4e-6 and divided by >= 1e-3, quotients (< 7e4) to ~8e-3
+    f.slack = 0.03f + 8e-6f * (__builtin_fabsf(f.near0) + __builtin_fabsf(f.far0));
+    return f;
+  }
+  // true when the estimate at distance t certainly returns the ground/sky term
+  // (renderer.cl:214 condition false) -- ground distance `g` = res.x there
+  RM_DEV bool surely_no_walk(const BoxFilter& f, float t, float g) {
+    if (!f.ok) return false;
+    const float m = f.slack + 8e-6f * __builtin_fabsf(t);
+    return g <= 0.0f                     // entry distance is >= 0 or -1: never < g
+           || f.far0 - t < -m            // box entirely behind: b < 0 <= a
+           || f.far0 - f.near0 < -m      // the line misses the box: b < a
+           || f.near0 - t > g + m;       // entry farther than the ground term
+  }
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
     r.distance = o.startDist;
+    BoxFilter flt;
+    flt.ok = false;
+    if (!COUNT) flt = make_filter(ro, rdir);
     while (--maxSteps >= 0) {
       r.pos = mads(rdir, r.distance, ro);
       float sd, scode;
-      scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd, scode, r.normal);
+      const float h = r.pos.y + o.groundY;  // renderer.cl:211
+      const float g = h < 1e5f ? h : 1e5f;
+      RM_WS(ws_iters++);
+      if (!COUNT && surely_no_walk(flt, r.distance, g)) {
+        RM_WS(ws_filtered++);
+        sd = g;
+        scode = h < 1e5f ? h : -1.0f;
+        r.normal = (g < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;  // renderer.cl:212
+      } else {
+        scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd, scode, r.normal);
+      }
       r.objectID = rmd::f2i(scode);
       if (__builtin_fabsf(sd) <= o.eps || r.distance >= maxDist) break;
       r.distance += sd;

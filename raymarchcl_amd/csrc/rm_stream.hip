@@ -33,6 +33,8 @@
 // HBM streaming traffic of ~1 KB per hit sample, written and read once.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
 #include "rm_stream.h"
@@ -203,6 +205,19 @@ __device__ __forceinline__ void store_hit(const StreamArgs& a, int level, int s,
 
 using Tr = rmk::Tracer<false, true>;
 
+#ifdef RM_WORK_STATS
+// debug: counters[16 + 8*kind + {0 rays,1 iters,2 filtered,3 walks,4 lookups,5 jumps}]
+__device__ __forceinline__ void flush_stats(const StreamArgs& a, int kind, Tr& tr, unsigned int rays) {
+  unsigned int v[6] = {rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups, tr.ws_jumps};
+  for (int k = 0; k < 6; k++) atomicAdd(a.counters + 16 + 8 * kind + k, v[k]);
+}
+#define RM_FLUSH(kind, tr, rays) flush_stats(a, kind, tr, rays)
+#define RM_WS_RAY (nrays++)
+#else
+#define RM_FLUSH(kind, tr, rays) ((void)0)
+#define RM_WS_RAY ((void)nrays)
+#endif
+
 // ---- stage 1: camera ray + primary march (renderer.cl:489-490, :413)
 __global__ __launch_bounds__(256) void primary_kernel(StreamArgs a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(256) void primary_kernel(StreamArgs a) {
   Tr::Hit h{};
   tr.march(c.eye, c.rd0, h, o.maxDist, o.maxIter, true);
   store_hit(a, 0, s, h.pos, h.distance, h.normal, h.objectID);
+  RM_FLUSH(0, tr, 1);
   if (h.distance >= o.maxDist) return;  // miss: combine_kernel shades the sky
   const rmk::Material m = rmk::material_of(o, h.objectID);
   const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(256) void primary_kernel(StreamArgs a) {
 
 // ---- stage 2 (x reflectIter): one reflection bounce (renderer.cl:389, :436-437)
 __global__ __launch_bounds__(256) void bounce_kernel(StreamArgs a, int q) {
+  unsigned int nrays = 0;
   const unsigned int total = a.counters[q ? C_BQ1 : C_BQ0];
   const RmOpts& o = a.opts_all[0];
   rmk::Scene sc{a.vox, a.mc_all, a.opts_all, a.dist8, a.surf32};
@@ -240,6 +257,7 @@ __global__ __launch_bounds__(256) void bounce_kernel(StreamArgs a, int q) {
     Tr::Hit h{};
     tr.march(org, dir, h, o.maxDist, o.maxIter, false);
     store_hit(a, 1 + bounce, s, h.pos, h.distance, h.normal, h.objectID);
+    RM_WS_RAY;
     if (h.objectID < 0) continue;
     const int pass = s / a.count, idx = s - pass * a.count;
     const int id = pixel_of(a, idx);
@@ -249,10 +267,12 @@ __global__ __launch_bounds__(256) void bounce_kernel(StreamArgs a, int q) {
                       !((double)rmk::material_of(o, h.objectID).r0 < 0.001);
     if (more) emit_bounce(a, q ^ 1, s, bounce + 1, dir, h.pos, h.normal);
   }
+  RM_FLUSH(1, tr, nrays);
 }
 
 // ---- stage 3: shadow rays (renderer.cl:292-301)
 __global__ __launch_bounds__(256) void shadow_kernel(StreamArgs a) {
+  unsigned int nrays = 0;
   const unsigned int total = a.counters[C_SQ];
   const RmOpts& o = a.opts_all[0];
   rmk::Scene sc{a.vox, a.mc_all, a.opts_all, a.dist8, a.surf32};
@@ -262,11 +282,14 @@ __global__ __launch_bounds__(256) void shadow_kernel(StreamArgs a) {
     Tr::Hit h{};
     tr.march(V(ta.x, ta.y, ta.z), V(tb.x, tb.y, tb.z), h, ta.w, o.shadowIter, false);
     a.sh[__float_as_int(tb.w)] = rmd::step_cl(ta.w, h.distance);
+    RM_WS_RAY;
   }
+  RM_FLUSH(2, tr, nrays);
 }
 
 // ---- stage 4: AO probes (renderer.cl:342)
 __global__ __launch_bounds__(256) void probe_kernel(StreamArgs a) {
+  unsigned int nrays = 0;
   const unsigned int total = a.counters[C_PQ];
   const RmOpts& o = a.opts_all[0];
   rmk::Scene sc{a.vox, a.mc_all, a.opts_all, a.dist8, a.surf32};
@@ -277,7 +300,9 @@ __global__ __launch_bounds__(256) void probe_kernel(StreamArgs a) {
     v3 nn;
     tr.scene_distance(V(ta.x, ta.y, ta.z), V(tb.x, tb.y, tb.z), o.maxVoxelIter / 2, false, sd, code, nn);
     a.ao[__float_as_int(ta.w)] = sd;
+    RM_WS_RAY;
   }
+  RM_FLUSH(3, tr, nrays);
 }
 
 // ---- stage 5: shading arithmetic of the sample, in the reference's order
@@ -448,6 +473,18 @@ hipError_t launch_stream_batch(hipStream_t st, const StreamLaunch& L) {
   shadow_kernel<<<grid, 256, 0, st>>>(a);
   probe_kernel<<<grid, 256, 0, st>>>(a);
   combine_kernel<<<per_sample, 256, 0, st>>>(a);
+#ifdef RM_WORK_STATS
+  {
+    unsigned int hc[64];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hc, a.counters, sizeof hc, hipMemcpyDeviceToHost);
+    const char* names[4] = {"primary", "bounce", "shadow", "probe"};
+    fprintf(stderr, "[stream stats] samples=%d queues: bq0=%u bq1=%u sq=%u pq=%u\n", a.samples, hc[0], hc[1], hc[2], hc[3]);
+    for (int k = 0; k < 4; k++)
+      fprintf(stderr, "  %-8s rays=%u iters=%u filtered=%u walks=%u lookups=%u jumps=%u\n", names[k],
+              hc[16 + 8 * k], hc[17 + 8 * k], hc[18 + 8 * k], hc[19 + 8 * k], hc[20 + 8 * k], hc[21 + 8 * k]);
+  }
+#endif
   return hipGetLastError();
 }
 
