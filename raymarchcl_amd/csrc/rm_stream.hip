@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void emit_kernel(StreamArgs a, int level, int 
 }
 
 // =========================== the ray engine ===========================
-enum : int { E_IDLE = 0, E_OUTER, E_NEEDX, E_WALK, E_HIT, E_FINISH, E_STATES };
+enum : int { E_IDLE = 0, E_OUTER, E_NEEDX, E_WALK, E_HIT };
 
 template <int KIND>
 __global__ __launch_bounds__(256) void engine_kernel(StreamArgs a, int q, int level) {
@@ -299,171 +299,58 @@ __global__ __launch_bounds__(256) void engine_kernel(StreamArgs a, int q, int le
   bool have_est = false;
 
   for (;;) {
-    // ---- vote: run the state most lanes are in
-    int best = -1, best_score = 0;
-#pragma unroll
-    for (int k = 0; k < E_STATES; k++) {
-      int c = __popcll(__ballot(st == k));
-      if (k == E_IDLE) {
-        if (drained) c = 0;
-        else if (c < 16 && c > 0) c = 0;  // refill in bulk ...
-      }
-      if (c > best_score) { best_score = c; best = k; }
-    }
-    if (best < 0) {
-      // ... or when nothing else can run
-      if (drained || __ballot(st == E_IDLE) == 0ull) break;
-      best = E_IDLE;
-    }
+    // ---- schedule.  The two common states (outer march step, voxel walk) run every
+    // turn for whoever is in them; the rare expensive ones (queue refill, exact slab
+    // test, surface decode) run only once enough lanes wait for them -- or nothing
+    // else is left to do -- so one lane's event never stalls the other 63.
+    const int nI = __popcll(__ballot(st == E_IDLE));
+    const int nO = __popcll(__ballot(st == E_OUTER));
+    const int nX = __popcll(__ballot(st == E_NEEDX));
+    const int nW = __popcll(__ballot(st == E_WALK));
+    const int nH = __popcll(__ballot(st == E_HIT));
+    const int busy = nO + nW;
+    if (busy + nX + nH == 0 && (drained || nI == 0)) break;
 
-    switch (best) {
-      case E_IDLE: {
-        const unsigned long long need = __ballot(st == E_IDLE);
-        const int cnt = __popcll(need);
-        unsigned int base = 0;
-        const int leader = __ffsll((long long)need) - 1;
-        if (lane == leader) base = atomicAdd(head, (unsigned int)cnt);
-        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-        if (base + (unsigned int)cnt >= total) drained = true;
-        if (st == E_IDLE) {
-          const unsigned int i = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
-          if (i < total) {
-            const float4* t = tasks + (size_t)i * 4;
-            const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-            ro = V(t0.x, t0.y, t0.z); maxDist = t0.w;
-            rd = V(t1.x, t1.y, t1.z); dest = __float_as_int(t1.w);
-            delta = V(t2.x, t2.y, t2.z); inv_s = t2.w;
-            near0 = t3.x; far0 = t3.y; slack = t3.z;
-            dist = o.startDist;  // renderer.cl:242
-            last_t = dist;
-            osteps = outer_steps;
-            have_est = false;
-            obj = 0;
-            st = E_OUTER;
-          }
-        }
-        break;
-      }
-      case E_OUTER: {
-        if (st == E_OUTER) {
-          bool fin = false;
-          if (have_est) {  // renderer.cl:246-250
-            have_est = false;
-            obj = rmd::f2i(est_code);
-            if (KIND == K_PROBE) fin = true;
-            else if (__builtin_fabsf(est_sd) <= o.eps || dist >= maxDist) fin = true;
-            else dist += est_sd;
-          }
-          if (!fin && --osteps < 0) fin = true;  // renderer.cl:243
-          if (fin) {
-            st = E_FINISH;
-          } else {
-            last_t = dist;
-            const float py = rd.y * dist + ro.y;  // y of renderer.cl:244
-            const float h = py + o.groundY;       // renderer.cl:211
-            g_rd = h < 1e5f ? h : 1e5f;
-            g_rc = h < 1e5f ? h : -1.0f;
-            nrm = (g_rd < 1e5f) ? V(0.f, 1.f, 0.f) : -rd;  // renderer.cl:212
-            const float m = slack + 8e-6f * __builtin_fabsf(dist);
-            const float tn = near0 - dist, tf = far0 - dist;
-            if (slack < 0.0f || walk_steps <= 0) {
-              st = E_NEEDX;
-            } else if (g_rd <= 0.0f || tf < -m || far0 - near0 < -m || tn > g_rd + m) {
-              have_est = true;  // renderer.cl:214 is certainly false: ground / sky term
-              est_sd = g_rd;
-              est_code = g_rc;
-            } else if (tn < -m && tf > m && g_rd > m) {
-              // certainly inside the clip box: the slab test returns exactly +0
-              p = (rmk::mads(rd, dist, ro) + rmk::ld3(o.voxelBounds)) * rmk::ld3(o.invVoxelScale);
-              wsteps = walk_steps;
-              st = E_WALK;
-            } else {
-              st = E_NEEDX;
-            }
-          }
-        }
-        break;
-      }
-      case E_NEEDX: {  // renderer.cl:213-218 evaluated exactly
-        if (st == E_NEEDX) {
-          const v3 rpos = rmk::mads(rd, dist, ro);
-          const float t_in = rmk::box_entry_of(o, rpos, rd);
-          if (t_in >= 0.0f && t_in < g_rd && walk_steps > 0) {
-            v3 pp = rpos + rmk::ld3(o.voxelBounds);
-            if (t_in > 0.0f) pp = rmk::mads(rd, t_in, pp);
-            p = pp * rmk::ld3(o.invVoxelScale);
-            wsteps = walk_steps;
-            st = E_WALK;
-          } else {
-            have_est = true;
-            est_sd = g_rd;
-            est_code = g_rc;
-            st = E_OUTER;
-          }
-        }
-        break;
-      }
-      case E_WALK: {  // renderer.cl:219-234, a few lookups per turn
-        if (st == E_WALK) {
-#pragma unroll 1
-          for (int turn = 0; turn < 4 && st == E_WALK; turn++) {
-            bool out = wsteps <= 0;
-            int dcell = 1;
-            if (!out) {
-              const int qx = rmd::convert_int_sat(p.x * frx);
-              const int qy = rmd::convert_int_sat(p.y * fry);
-              const int qz = rmd::convert_int_sat(p.z * frz);
-              out = !rmk::in_grid_of(o, qx, qy, qz);
-              if (!out) {
-                cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
-                dcell = a.dist8[cell];
-              }
-            }
-            if (out) {
-              have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
-            } else if (dcell == 0) {
-              st = E_HIT;
-            } else {
-              // samples 1 .. j-1 from here are certainly in empty in-bounds cells
-              int j = (int)((float)(dcell - 2) * inv_s);
-              bool moved = false;
-              if (j >= 2 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
-                if (j >= wsteps) {  // the walk ends before it can reach anything
-                  have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
-                  moved = true;
-                } else if (j >= 8) {
-                  if (rmk::advance_exact(p, delta, j)) { wsteps -= j; moved = true; }
-                  else j >>= 2;
-                }
-                if (!moved && j >= 2) {  // short skips: the reference's own adds, no fetches
-                  const int jj = j > 7 ? 7 : j;
-                  for (int k = 0; k < jj; k++) p = p + delta;
-                  wsteps -= jj;
-                  moved = true;
-                }
-              }
-              if (!moved) { p = p + delta; wsteps -= 1; }
-            }
-          }
-        }
-        break;
-      }
-      case E_HIT: {  // renderer.cl:222-231 via surf32
-        if (st == E_HIT) {
-          const uint32_t w = a.surf32[cell];
-          const int v = (int)(w & 0xffu);
-          nrm = rmk::surf_normal(w, smooth);
-          const v3 rpos = rmk::mads(rd, last_t, ro);
-          const v3 hit = rmk::madv(p, rmk::ld3(o.voxelBounds2), -rmk::ld3(o.voxelBounds));
-          const float d = rmk::length(rpos - hit) - o.voxelSize;
-          if (d < g_rd) { g_rd = d; g_rc = rmk::band_of(v); }
-          have_est = true; est_sd = g_rd; est_code = g_rc;
+    if (!drained && (nI >= 16 || (nI > 0 && busy + nX + nH == 0))) {  // ---- refill
+      const unsigned long long need = __ballot(st == E_IDLE);
+      const int cnt = __popcll(need);
+      unsigned int base = 0;
+      const int leader = __ffsll((long long)need) - 1;
+      if (lane == leader) base = atomicAdd(head, (unsigned int)cnt);
+      base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+      if (base + (unsigned int)cnt >= total) drained = true;
+      if (st == E_IDLE) {
+        const unsigned int i = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+        if (i < total) {
+          const float4* t = tasks + (size_t)i * 4;
+          const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+          ro = V(t0.x, t0.y, t0.z); maxDist = t0.w;
+          rd = V(t1.x, t1.y, t1.z); dest = __float_as_int(t1.w);
+          delta = V(t2.x, t2.y, t2.z); inv_s = t2.w;
+          near0 = t3.x; far0 = t3.y; slack = t3.z;
+          dist = o.startDist;  // renderer.cl:242
+          last_t = dist;
+          osteps = outer_steps;
+          have_est = false;
+          obj = 0;
           st = E_OUTER;
         }
-        break;
       }
-      default: {  // E_FINISH: renderer.cl:252-256 and the consumer of the ray
-        if (st == E_FINISH) {
+    }
+
+    if (nO > 0 && st == E_OUTER) {  // ---- outer march: a few steps while they stay cheap
+#pragma unroll 1
+      for (int turn = 0; turn < 3 && st == E_OUTER; turn++) {
+        bool fin = false;
+        if (have_est) {  // renderer.cl:246-250
+          have_est = false;
+          obj = rmd::f2i(est_code);
+          if (KIND == K_PROBE) fin = true;
+          else if (__builtin_fabsf(est_sd) <= o.eps || dist >= maxDist) fin = true;
+          else dist += est_sd;
+        }
+        if (!fin && --osteps < 0) fin = true;  // renderer.cl:243
+        if (fin) {  // renderer.cl:252-256 and the consumer of the ray
           if (KIND == K_PROBE) {
             a.ao[dest] = est_sd;
           } else {
@@ -480,10 +367,121 @@ __global__ __launch_bounds__(256) void engine_kernel(StreamArgs a, int q, int le
             }
           }
           st = E_IDLE;
+        } else {
+          last_t = dist;
+          const float py = rd.y * dist + ro.y;  // y of renderer.cl:244
+          const float h = py + o.groundY;       // renderer.cl:211
+          g_rd = h < 1e5f ? h : 1e5f;
+          g_rc = h < 1e5f ? h : -1.0f;
+          nrm = (g_rd < 1e5f) ? V(0.f, 1.f, 0.f) : -rd;  // renderer.cl:212
+          const float m = slack + 8e-6f * __builtin_fabsf(dist);
+          const float tn = near0 - dist, tf = far0 - dist;
+          if (slack < 0.0f || walk_steps <= 0) {
+            st = E_NEEDX;
+          } else if (g_rd <= 0.0f || tf < -m || far0 - near0 < -m || tn > g_rd + m) {
+            have_est = true;  // renderer.cl:214 is certainly false: ground / sky term
+            est_sd = g_rd;
+            est_code = g_rc;
+          } else if (tn < -m && tf > m && g_rd > m) {
+            // certainly inside the clip box: the slab test returns exactly +0
+            p = (rmk::mads(rd, dist, ro) + rmk::ld3(o.voxelBounds)) * rmk::ld3(o.invVoxelScale);
+            wsteps = walk_steps;
+            st = E_WALK;
+          } else {
+            st = E_NEEDX;
+          }
         }
-        break;
       }
     }
+
+    if ((nX >= 8 || (nX > 0 && busy == 0)) && st == E_NEEDX) {  // ---- renderer.cl:213-218, exact
+      const v3 rpos = rmk::mads(rd, dist, ro);
+      const float t_in = rmk::box_entry_of(o, rpos, rd);
+      if (t_in >= 0.0f && t_in < g_rd && walk_steps > 0) {
+        v3 pp = rpos + rmk::ld3(o.voxelBounds);
+        if (t_in > 0.0f) pp = rmk::mads(rd, t_in, pp);
+        p = pp * rmk::ld3(o.invVoxelScale);
+        wsteps = walk_steps;
+        st = E_WALK;
+      } else {
+        have_est = true;
+        est_sd = g_rd;
+        est_code = g_rc;
+        st = E_OUTER;
+      }
+    }
+
+    if (nW > 0 && st == E_WALK) {  // ---- renderer.cl:219-234, a few lookups per turn
+#pragma unroll 1
+      for (int turn = 0; turn < 4 && st == E_WALK; turn++) {
+        bool out = wsteps <= 0;
+        int dcell = 1;
+        if (!out) {
+          const int qx = rmd::convert_int_sat(p.x * frx);
+          const int qy = rmd::convert_int_sat(p.y * fry);
+          const int qz = rmd::convert_int_sat(p.z * frz);
+          out = !rmk::in_grid_of(o, qx, qy, qz);
+          if (!out) {
+            cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
+            dcell = a.dist8[cell];
+          }
+        }
+        if (out) {
+          have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
+        } else if (dcell == 0) {
+          st = E_HIT;
+        } else {
+          // samples 1 .. j-1 from here are certainly in empty in-bounds cells
+          int j = (int)((float)(dcell - 2) * inv_s);
+          bool moved = false;
+          if (j >= 2 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
+            if (j >= wsteps) {  // the walk ends before it can reach anything
+              have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
+              moved = true;
+            } else if (j >= 8) {
+              if (rmk::advance_exact(p, delta, j)) { wsteps -= j; moved = true; }
+              else j >>= 2;
+            }
+            if (!moved && j >= 2) {  // short skips: the reference's own adds, no fetches
+              const int jj = j > 7 ? 7 : j;
+              for (int k = 0; k < jj; k++) p = p + delta;
+              wsteps -= jj;
+              moved = true;
+            }
+          }
+          if (!moved) { p = p + delta; wsteps -= 1; }
+        }
+      }
+    }
+
+    if ((nH >= 8 || (nH > 0 && busy == 0)) && st == E_HIT) {  // ---- renderer.cl:222-231 via surf32
+      const uint32_t w = a.surf32[cell];
+      const int v = (int)(w & 0xffu);
+      nrm = rmk::surf_normal(w, smooth);
+      const v3 rpos = rmk::mads(rd, last_t, ro);
+      const v3 hit = rmk::madv(p, rmk::ld3(o.voxelBounds2), -rmk::ld3(o.voxelBounds));
+      const float d = rmk::length(rpos - hit) - o.voxelSize;
+      if (d < g_rd) { g_rd = d; g_rc = rmk::band_of(v); }
+      have_est = true; est_sd = g_rd; est_code = g_rc;
+      st = E_OUTER;
+    }
+  }
+}
+
+// ---- AO probes (renderer.cl:342): one short walk each, uniform enough that a plain
+// one-lane-per-probe kernel beats the engine's scheduling overhead (measured)
+__global__ __launch_bounds__(256) void probe_kernel(StreamArgs a) {
+  const unsigned int total = a.counters[Q_PROBE];
+  const RmOpts& o = a.opts_all[0];
+  rmk::Scene sc{a.vox, a.mc_all, a.opts_all, a.dist8, a.surf32};
+  rmk::Tracer<false, true> tr(sc);
+  const float4* __restrict__ tasks = a.q[Q_PROBE];
+  for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const float4 t0 = tasks[(size_t)i * 4], t1 = tasks[(size_t)i * 4 + 1];
+    float sd, code;
+    v3 nn;
+    tr.scene_distance(V(t0.x, t0.y, t0.z), V(t1.x, t1.y, t1.z), o.maxVoxelIter / 2, false, sd, code, nn);
+    a.ao[__float_as_int(t1.w)] = sd;
   }
 }
 
@@ -661,7 +659,7 @@ hipError_t launch_stream_batch(hipStream_t st, const StreamLaunch& L) {
     if (lvl + 1 < L.levels) engine_kernel<K_BOUNCE><<<grid, 256, 0, st>>>(a, bq_out, lvl + 1);
   }
   engine_kernel<K_SHADOW><<<grid, 256, 0, st>>>(a, Q_SHADOW, 0);
-  engine_kernel<K_PROBE><<<grid, 256, 0, st>>>(a, Q_PROBE, 0);
+  probe_kernel<<<grid, 256, 0, st>>>(a);
   combine_kernel<<<per_sample, 256, 0, st>>>(a);
   return hipGetLastError();
 }
