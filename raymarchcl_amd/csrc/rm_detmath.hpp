@@ -50,11 +50,12 @@ RM_DEV uint32_t f2u(float x) {
 #endif
 }
 RM_DEV int32_t convert_int_sat(float x) {
-  // v_cvt_i32_f32 already truncates, saturates and maps NaN to 0.
-  if (x != x) return 0;
-  if (x >= 2147483648.0f) return INT32_MAX;
-  if (x <= -2147483648.0f) return INT32_MIN;
-  return (int32_t)x;
+  // OpenCL convert_int_sat(float): truncate, saturate, NaN -> 0 -- which is exactly
+  // what the hardware's v_cvt_i32_f32 does.  Spelled as the instruction itself so
+  // that the compiler cannot treat an out-of-range (int) cast as undefined.
+  int32_t r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 RM_DEV double bits2d(uint64_t u) { return __longlong_as_double((long long)u); }

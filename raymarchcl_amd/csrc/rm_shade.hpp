@@ -113,9 +113,9 @@ RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
   const float b = rmd::fmin_cl(fx, rmd::fmin_cl(fy, fz));
   return b > a ? a : -1.0f;
 }
-RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {
-  return qz >= 0 && qz < o.voxelRes[2] && qy >= 0 && qy < o.voxelRes[1] && qx >= 0 &&
-         qx < o.voxelRes[0];
+RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {  // 0 <= q < res per axis
+  return (unsigned)qz < (unsigned)o.voxelRes[2] && (unsigned)qy < (unsigned)o.voxelRes[1] &&
+         (unsigned)qx < (unsigned)o.voxelRes[0];
 }
 // renderer.cl:259-261
 RM_DEV v3 sky_of(const RmOpts& o, v3 dir) {
@@ -153,6 +153,52 @@ RM_DEV v3 surf_normal(uint32_t w, bool smooth) {
                      -(float)((int)((w >> 30) & 3u) - 1)));
 }
 RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }  // renderer.cl:205-207
+
+// One sample of the accelerated fixed-step walk (renderer.cl:219-234): look the
+// sample at p up in dist8 and move on.  `steps` = samples left including this one.
+// Returns 0: keep walking, 1: this sample is a hit (*cell_out = its cell, p kept),
+// 2: the walk ends without a hit (out of samples / left the grid / cannot reach
+// anything in the samples left).
+//
+// Skip length: dist8 = d at cell q means every cell within Chebyshev distance d-1
+// of q is empty and inside the grid.  Sample k lies <= k*s cells from sample 0
+// along the fastest axis (s = cells per sample), so its cell differs from q by at
+// most floor(k*s + eps) + 1; samples 1 .. j-1 are therefore certainly empty for
+// j = 1 + floor(0.98 * (d-1) / s)   (inv_s = 0.98 / s; the 2 % absorb the <= 0.01
+// cell of accumulated rounding drift and the rounding of p*res).
+RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
+                     float inv_s, int* cell_out) {
+  if (steps <= 0) return 2;
+  const int qx = rmd::convert_int_sat(p.x * (float)o.voxelRes[0]);
+  const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
+  const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
+  if (!in_grid_of(o, qx, qy, qz)) return 2;  // renderer.cl:221
+  const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
+  const int d = dist8[cell];
+  if (d == 0) {
+    *cell_out = cell;
+    return 1;
+  }
+  int j = 1 + (int)((float)(d - 1) * inv_s);
+  // (the floor argument above needs p >= 0; tiny p also means tiny binades)
+  if (j >= 2 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
+    if (j >= steps) return 2;
+    if (j >= 8) {
+      if (advance_exact(p, delta, j)) {
+        steps -= j;
+        return 0;
+      }
+      j >>= 2;
+    }
+    const int jj = j > 7 ? 7 : j;  // short skips: the reference's own adds, no fetches
+    for (int k = 0; k < jj; k++) p = p + delta;
+    steps -= jj;
+    return 0;
+  }
+  p = p + delta;
+  steps -= 1;
+  return 0;
+}
 
 template <bool COUNT, bool ACCEL = false>
 struct Tracer {
@@ -234,33 +280,20 @@ struct Tracer {
                               __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
         RM_WS(ws_walks++);
-        while (steps > 0) {
-          const int qx = rmd::convert_int_sat(p.x * frx);
-          const int qy = rmd::convert_int_sat(p.y * fry);
-          const int qz = rmd::convert_int_sat(p.z * frz);
-          if (!in_grid(qx, qy, qz)) break;
-          const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
-          const int dcell = sc.dist[cell];
+        (void)s;
+        for (;;) {
+          int cell = 0;
           RM_WS(ws_lookups++);
-          if (dcell == 0) {
+          const int r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
+          if (r == 0) continue;
+          if (r == 1) {
             const uint32_t w = sc.surf[cell];
-            const int v = (int)(w & 0xffu);
             nrm = surf_normal(w, smooth);
             const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
             const float d = length(rpos - hit) - o.voxelSize;
-            if (d < rd) { rd = d; rc = v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }
-            break;
+            if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }
           }
-          // samples k = 1 .. j-1 from here are certainly in empty in-bounds cells
-          int j = (int)((float)(dcell - 2) * inv_s);
-          if (j >= 4 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
-            if (j >= steps) break;  // the walk ends before it can reach anything
-            if (advance_exact(p, delta, j)) { steps -= j; RM_WS(ws_jumps++); continue; }
-            j = j >> 2;
-            if (j >= 4 && advance_exact(p, delta, j)) { steps -= j; RM_WS(ws_jumps++); continue; }
-          }
-          p = p + delta;
-          steps -= 1;
+          break;
         }
       } else
       while (--steps >= 0) {

@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256) void engine_kernel(StreamArgs a, int q, int le
   unsigned int* __restrict__ head = a.counters + 8 + q;
   const float4* __restrict__ tasks = a.q[q];
   const int lane = threadIdx.x & 63;
-  const float frx = (float)o.voxelRes[0], fry = (float)o.voxelRes[1], frz = (float)o.voxelRes[2];
   const int walk_steps = KIND == K_PROBE ? o.maxVoxelIter / 2 : o.maxVoxelIter;
   const int outer_steps = KIND == K_PROBE ? 1 : (KIND == K_SHADOW ? o.shadowIter : o.maxIter);
   const bool smooth = KIND == K_PRIMARY;
@@ -414,42 +413,11 @@ __global__ __launch_bounds__(256) void engine_kernel(StreamArgs a, int q, int le
     if (nW > 0 && st == E_WALK) {  // ---- renderer.cl:219-234, a few lookups per turn
 #pragma unroll 1
       for (int turn = 0; turn < 4 && st == E_WALK; turn++) {
-        bool out = wsteps <= 0;
-        int dcell = 1;
-        if (!out) {
-          const int qx = rmd::convert_int_sat(p.x * frx);
-          const int qy = rmd::convert_int_sat(p.y * fry);
-          const int qz = rmd::convert_int_sat(p.z * frz);
-          out = !rmk::in_grid_of(o, qx, qy, qz);
-          if (!out) {
-            cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
-            dcell = a.dist8[cell];
-          }
-        }
-        if (out) {
-          have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
-        } else if (dcell == 0) {
+        const int r = rmk::walk_step(o, a.dist8, p, wsteps, delta, inv_s, &cell);
+        if (r == 1) {
           st = E_HIT;
-        } else {
-          // samples 1 .. j-1 from here are certainly in empty in-bounds cells
-          int j = (int)((float)(dcell - 2) * inv_s);
-          bool moved = false;
-          if (j >= 2 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
-            if (j >= wsteps) {  // the walk ends before it can reach anything
-              have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
-              moved = true;
-            } else if (j >= 8) {
-              if (rmk::advance_exact(p, delta, j)) { wsteps -= j; moved = true; }
-              else j >>= 2;
-            }
-            if (!moved && j >= 2) {  // short skips: the reference's own adds, no fetches
-              const int jj = j > 7 ? 7 : j;
-              for (int k = 0; k < jj; k++) p = p + delta;
-              wsteps -= jj;
-              moved = true;
-            }
-          }
-          if (!moved) { p = p + delta; wsteps -= 1; }
+        } else if (r == 2) {
+          have_est = true; est_sd = g_rd; est_code = g_rc; st = E_OUTER;
         }
       }
     }

@@ -178,41 +178,24 @@ struct WaveTracer {
   // The hot loop: at most `budget` lookups of the fixed-step march
   // (renderer.cl:219-234) for a lane with marching == true.
   RM_DEV void march_some(WaveLane& L, int budget) {
-    const float frx = (float)o.voxelRes[0], fry = (float)o.voxelRes[1], frz = (float)o.voxelRes[2];
     v3 p = L.p;
     int steps = L.msteps;
     bool done = false;
-    while (budget-- > 0) {
-      if (steps <= 0) { done = true; break; }
-      const int qx = rmd::convert_int_sat(p.x * frx);
-      const int qy = rmd::convert_int_sat(p.y * fry);
-      const int qz = rmd::convert_int_sat(p.z * frz);
-      if (!leaf.in_grid(qx, qy, qz)) { done = true; break; }
-      const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
-      const int dcell = a.dist8[cell];
-      if (dcell == 0) {
+    while (budget-- > 0 && !done) {
+      int cell = 0;
+      const int r = walk_step(o, a.dist8, p, steps, L.delta, L.inv_s, &cell);
+      if (r == 1) {
         const uint32_t w = a.surf32[cell];
-        const int v = (int)(w & 0xffu);
         L.nrm = surf_normal(w, L.smooth);
         const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
         const float d = length(L.rpos - hit) - o.voxelSize;
-        if (d < L.g_rd) { L.g_rd = d; L.g_rc = band_of(v); }
-        done = true;
-        break;
+        if (d < L.g_rd) { L.g_rd = d; L.g_rc = band_of((int)(w & 0xffu)); }
       }
-      int j = (int)((float)(dcell - 2) * L.inv_s);
-      if (j >= 4 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
-        if (j >= steps) { done = true; break; }
-        if (advance_exact(p, L.delta, j)) { steps -= j; continue; }
-        j = j >> 2;
-        if (j >= 4 && advance_exact(p, L.delta, j)) { steps -= j; continue; }
-      }
-      p = p + L.delta;
-      steps -= 1;
+      done = r != 0;
     }
     L.p = p;
     L.msteps = steps;
-    if (done || steps <= 0) finish_estimate(L);
+    if (done) finish_estimate(L);
   }
 
   RM_DEV void start_ray(WaveLane& L, int kind, v3 dir, float maxDist, int maxSteps) {
