@@ -69,8 +69,10 @@ struct rm_ctx {
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
   DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf;
-  int stream_mode = 1;                 // RAYMARCH_KERNEL=stream (default) | straight | wave
+  int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
+  int straight_waves = 8;  // RAYMARCH_STRAIGHT_WAVES (3..8): waves/SIMD the register budget of
+                           // render_samples_kernel leaves room for (8 = 64 VGPRs + scratch spills)
   int wave_mode = 0;    // RAYMARCH_KERNEL=wave -> persistent wave-scheduled kernel (experimental)
   int min_waves = 4;    // RAYMARCH_WAVES=2..5: register budget of the wave kernel
   int wave_blocks = 0;  // persistent grid size
@@ -255,7 +257,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel,
                                          d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx,
                                          i1 - i0, staging + (size_t)i0 * count * 4, n, tile_first,
-                                         tile_stride));
+                                         tile_stride, c->straight_waves));
     }
     launches++;
     i0 = i1;
@@ -313,7 +315,9 @@ int rm_create(int device_id, rm_ctx** out) {
   c->use_accel = !(na && na[0] == '1');
   const char* km = getenv("RAYMARCH_KERNEL");
   c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
-  c->stream_mode = !km || strcmp(km, "stream") == 0;
+  c->stream_mode = km && strcmp(km, "stream") == 0;  // experimental task-queue pipeline
+  const char* sw = getenv("RAYMARCH_STRAIGHT_WAVES");
+  if (sw && atoi(sw) >= 3 && atoi(sw) <= 8) c->straight_waves = atoi(sw);
   const char* bs = getenv("RAYMARCH_BATCH_SAMPLES");
   if (bs && atoll(bs) > 0) c->batch_samples = atoll(bs);
   const char* mw = getenv("RAYMARCH_WAVES");

@@ -23,7 +23,8 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
 // all `iter` passes of a partition in one launch -> staging [iter][tiles_per_part*64] float4
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel accel,
                                  const float* d_mc_all, const RmOpts* d_opts_all, int resx, int iter,
-                                 float* d_staging, int n, int tile_first, int tile_stride);
+                                 float* d_staging, int n, int tile_first, int tile_stride,
+                                 int min_waves = 3);
 // the same, by the persistent wave-scheduled kernel (needs the accel structures and
 // option records that differ only in .time); d_queue: one device uint32 of scratch
 hipError_t launch_render_wave(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,

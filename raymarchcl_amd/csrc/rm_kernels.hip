@@ -95,8 +95,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
 // per-pass tail (waves of the next pass fill the CUs while expensive tiles of
 // the previous one finish) and costs the same 32 B per sample the reference
 // spends on its read-modify-write of the accumulator.
-template <bool ACCEL>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void render_samples_kernel(
+template <bool ACCEL, int MINW>
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
     const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
@@ -308,7 +308,7 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
 
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
                                  const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
-                                 int tile_first, int tile_stride) {
+                                 int tile_first, int tile_stride, int min_waves) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
@@ -320,10 +320,16 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
   const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
   float4* st4 = reinterpret_cast<float4*>(staging);
   if (accel.dist && accel.surf)
-    render_samples_kernel<true><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all,
-                                                        st4, n, tile_first, tile_stride, tpp);
+    switch (min_waves) {
+      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+    }
   else
-    render_samples_kernel<false><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
+    render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
                                                          n, tile_first, tile_stride, tpp);
   return hipGetLastError();
 }

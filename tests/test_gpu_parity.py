@@ -190,9 +190,12 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
     want, want_argb = oracle_mod.render_frame(sc["vox"], opts, sc["mc"], n)
     for env in ({}, {"RAYMARCH_KERNEL": "stream", "RAYMARCH_BATCH_SAMPLES": "4000"},
                 {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "2"},
-                {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "4"}, {"RAYMARCH_KERNEL": "straight"},
+                {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "4"}, {"RAYMARCH_KERNEL": "stream"},
+                {"RAYMARCH_KERNEL": "straight", "RAYMARCH_STRAIGHT_WAVES": "3"},
+                {"RAYMARCH_KERNEL": "straight", "RAYMARCH_STRAIGHT_WAVES": "5"},
                 {"RAYMARCH_NO_ACCEL": "1"}, {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVE_BLOCKS": "3"}):
-        for k in ("RAYMARCH_WAVES", "RAYMARCH_KERNEL", "RAYMARCH_NO_ACCEL", "RAYMARCH_WAVE_BLOCKS"):
+        for k in ("RAYMARCH_WAVES", "RAYMARCH_KERNEL", "RAYMARCH_NO_ACCEL", "RAYMARCH_WAVE_BLOCKS",
+                  "RAYMARCH_BATCH_SAMPLES", "RAYMARCH_STRAIGHT_WAVES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
