@@ -71,6 +71,8 @@ struct rm_ctx {
   DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
+  int split_mode = 0;      // RAYMARCH_KERNEL=split: march chain and lighting as two launches
+  int split_tw = 8, split_lw = 8;  // RAYMARCH_SPLIT_WAVES=t,l
   int straight_waves = 8;  // RAYMARCH_STRAIGHT_WAVES (3..8): waves/SIMD the register budget of
                            // render_samples_kernel leaves room for (8 = 64 VGPRs + scratch spills)
   int wave_mode = 0;    // RAYMARCH_KERNEL=wave -> persistent wave-scheduled kernel (experimental)
@@ -246,6 +248,17 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       i0 = i1;
       continue;
     }
+    if (c->split_mode && c->use_accel) {
+      const int levels = 1 + (h0.reflectIter > 0 ? h0.reflectIter : 0);
+      HIP_TRY(c->work_buf.reserve((size_t)levels * (i1 - i0) * count * 32));
+      HIP_TRY(rmk::launch_render_split(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
+                                       d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4,
+                                       static_cast<float*>(c->work_buf.p), n, tile_first, tile_stride,
+                                       c->split_tw, c->split_lw));
+      launches++;
+      i0 = i1;
+      continue;
+    }
     if (wave) {
       HIP_TRY(c->queue_buf.reserve(64));
       HIP_TRY(rmk::launch_render_wave(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
@@ -316,6 +329,9 @@ int rm_create(int device_id, rm_ctx** out) {
   const char* km = getenv("RAYMARCH_KERNEL");
   c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
   c->stream_mode = km && strcmp(km, "stream") == 0;  // experimental task-queue pipeline
+  c->split_mode = km && strcmp(km, "split") == 0;
+  const char* spw = getenv("RAYMARCH_SPLIT_WAVES");
+  if (spw) sscanf(spw, "%d,%d", &c->split_tw, &c->split_lw);
   const char* sw = getenv("RAYMARCH_STRAIGHT_WAVES");
   if (sw && atoi(sw) >= 3 && atoi(sw) <= 8) c->straight_waves = atoi(sw);
   const char* bs = getenv("RAYMARCH_BATCH_SAMPLES");

@@ -25,6 +25,12 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel acc
                                  const float* d_mc_all, const RmOpts* d_opts_all, int resx, int iter,
                                  float* d_staging, int n, int tile_first, int tile_stride,
                                  int min_waves = 3);
+// the same in two launches (march chain -> hit records in d_hits -> lighting);
+// d_hits: (1 + reflectIter) * iter * tiles_per_part * 64 * 32 bytes
+hipError_t launch_render_split(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,
+                               const RmOpts* d_opts_all, int resx, int iter, float* d_staging,
+                               float* d_hits, int n, int tile_first, int tile_stride, int waves_trace,
+                               int waves_light);
 // the same, by the persistent wave-scheduled kernel (needs the accel structures and
 // option records that differ only in .time); d_queue: one device uint32 of scratch
 hipError_t launch_render_wave(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,

@@ -117,6 +117,54 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   staging[((long long)pass * tiles_per_part + slot) * 64 + lane] = make_float4(col.x, col.y, col.z, 1.0f);
 }
 
+// The two halves of a sample (Tracer::trace_chain / shade_from_hits): same grid
+// and tile order as render_samples_kernel, hit records in HBM in between.
+template <int MINW>
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void trace_chain_kernel(
+    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
+    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
+    const RmOpts* __restrict__ opts_all, float4* __restrict__ hits, int n, int tile_first,
+    int tile_stride, int tiles_per_part) {
+  const int pass = blockIdx.y;
+  const RmOpts* __restrict__ opts = opts_all + pass;
+  const int resx = opts->resolution[0];
+  const TileGeom g = tile_geom(resx, n);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long tile = tile_first + slot * tile_stride;
+  if (tile >= g.tiles_total) return;
+  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, 0, n);
+  if (id < 0) return;
+  rmk::Scene sc{vox, mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts, dist8, surf32};
+  rmk::Tracer<false, true> tr(sc);
+  const size_t samples = (size_t)gridDim.y * tiles_per_part * 64;
+  tr.trace_chain(id, hits, samples, ((size_t)pass * tiles_per_part + slot) * 64 + lane);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void light_kernel(
+    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
+    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
+    const RmOpts* __restrict__ opts_all, const float4* __restrict__ hits,
+    float4* __restrict__ staging, int n, int tile_first, int tile_stride, int tiles_per_part) {
+  const int pass = blockIdx.y;
+  const RmOpts* __restrict__ opts = opts_all + pass;
+  const int resx = opts->resolution[0];
+  const TileGeom g = tile_geom(resx, n);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long tile = tile_first + slot * tile_stride;
+  if (tile >= g.tiles_total) return;
+  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, 0, n);
+  if (id < 0) return;
+  rmk::Scene sc{vox, mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts, dist8, surf32};
+  rmk::Tracer<false, true> tr(sc);
+  const size_t samples = (size_t)gridDim.y * tiles_per_part * 64;
+  const size_t sidx = ((size_t)pass * tiles_per_part + slot) * 64 + lane;
+  const rmk::v3 col = tr.shade_from_hits(id, hits, samples, sidx);
+  staging[sidx] = make_float4(col.x, col.y, col.z, 1.0f);
+}
+
 // Persistent, wave-scheduled renderer (rm_wave.hpp): each wavefront pulls tiles
 // from a queue, keeps a pool of (pixel, pass) samples of its tile, and
 // alternates between one shared march loop and short per-lane continuations.
@@ -331,6 +379,40 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
   else
     render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
                                                          n, tile_first, tile_stride, tpp);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_split(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
+                               const RmOpts* d_opts_all, int resx, int iter, float* staging,
+                               float* hits, int n, int tile_first, int tile_stride, int waves_trace,
+                               int waves_light) {
+  const TileGeom g = tile_geom(resx, n);
+  if (tile_stride < 1) tile_stride = 1;
+  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
+  const long long my_tiles =
+      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
+  if (my_tiles == 0 || iter <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((my_tiles + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)iter);
+  const dim3 block(64 * kWavesPerBlock);
+  const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
+  float4* st4 = reinterpret_cast<float4*>(staging);
+  float4* h4 = reinterpret_cast<float4*>(hits);
+#define RM_T(W) trace_chain_kernel<W><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, h4, n, tile_first, tile_stride, tpp)
+#define RM_L(W) light_kernel<W><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, h4, st4, n, tile_first, tile_stride, tpp)
+  switch (waves_trace) {
+    case 4: RM_T(4); break;
+    case 6: RM_T(6); break;
+    default: RM_T(8); break;
+  }
+  switch (waves_light) {
+    case 4: RM_L(4); break;
+    case 5: RM_L(5); break;
+    case 6: RM_L(6); break;
+    case 7: RM_L(7); break;
+    default: RM_L(8); break;
+  }
+#undef RM_T
+#undef RM_L
   return hipGetLastError();
 }
 

@@ -554,6 +554,85 @@ struct Tracer {
     return normalize(right * vx + upv * vy + fwd);
   }
 
+  // ---- the same sample split in two at its only long-lived values ----
+  // Register pressure of shade() peaks inside a shadow march nested in the
+  // lighting of a reflection nested in the primary shading (~140 VGPRs, 3 waves
+  // per SIMD; or 64 VGPRs + heavy scratch traffic).  The primary march and the
+  // reflection marches do not depend on any lighting result (bounce k+1 needs only
+  // the hit of bounce k, renderer.cl:433-437), so they can run first and leave
+  // 32 B per hit in HBM; the lighting pass then never holds a march of its own
+  // caller.  Both halves evaluate exactly the expressions of sample_colour().
+  // hits: [level][samples] x 2 float4 = (pos, distance) (normal, objectID bits).
+  RM_DEV void trace_chain(int id, float4* __restrict__ hits, size_t samples, size_t sidx) {
+    const RmOpts& o = *sc.o;
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    Hit h{};
+    march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
+    hits[sidx * 2] = make_float4(h.pos.x, h.pos.y, h.pos.z, h.distance);
+    hits[sidx * 2 + 1] = make_float4(h.normal.x, h.normal.y, h.normal.z, __int_as_float(h.objectID));
+    if (h.distance >= o.maxDist) return;
+    const Material m = material(h.objectID);
+    if (!(m.r0 > 0.0f && o.reflectIter > 0)) return;
+    const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+    Hit rh{};
+    rh.pos = h.pos;
+    rh.normal = mads(s.mcNormal, k, h.normal);
+    v3 dir = rdir;
+    for (int i = 0; i < o.reflectIter; i++) {
+      dir = reflect(dir, rh.normal);
+      const v3 from = mads(dir, 0.0075f, rh.pos);
+      march(from, dir, rh, o.maxDist, o.maxIter, false);
+      float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
+      hk[0] = make_float4(rh.pos.x, rh.pos.y, rh.pos.z, rh.distance);
+      hk[1] = make_float4(rh.normal.x, rh.normal.y, rh.normal.z, __int_as_float(rh.objectID));
+      if (rh.objectID < 0) break;
+      if ((double)material(rh.objectID).r0 < 0.001) break;
+    }
+  }
+  RM_DEV v3 shade_from_hits(int id, const float4* __restrict__ hits, size_t samples, size_t sidx) {
+    const RmOpts& o = *sc.o;
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    const float4 ha = hits[sidx * 2], hb = hits[sidx * 2 + 1];
+    const float hdist = ha.w;
+    v3 col;
+    if (hdist >= o.maxDist) {
+      col = sky(rdir);
+    } else {
+      const v3 hpos = V(ha.x, ha.y, ha.z);
+      const Material m = material(__float_as_int(hb.w));
+      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      const v3 norm = mads(s.mcNormal, k, V(hb.x, hb.y, hb.z));
+      v3 refl = V(0.f, 0.f, 0.f);
+      if (m.r0 > 0.0f && o.reflectIter > 0) {
+        v3 lpos = hpos, lnrm = norm, dir = rdir;
+        for (int i = 0; i < o.reflectIter; i++) {
+          dir = reflect(dir, lnrm);
+          const v3 from = mads(dir, 0.0075f, lpos);
+          const float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
+          const float4 ka = hk[0], kb = hk[1];
+          const int obj = __float_as_int(kb.w);
+          lpos = V(ka.x, ka.y, ka.z);
+          lnrm = V(kb.x, kb.y, kb.z);
+          v3 bc;
+          if (obj < 0) {
+            bc = sky(dir);
+          } else {
+            bc = lighting(s, dir, lpos, material(obj), lnrm, sky(reflect(dir, lnrm)));
+          }
+          refl = refl + atmosphere(s, from, dir, ka.w, bc);
+          if (obj < 0) break;
+          if ((double)material(obj).r0 < 0.001) break;
+        }
+      } else {
+        refl = sky(reflect(rdir, norm));
+      }
+      col = lighting(s, rdir, hpos, m, norm, refl);
+    }
+    return atmosphere(s, s.eye, rdir, hdist, col) * o.exposure;
+  }
+
   // colour * exposure of work-item `id` (the value RenderImage blends in, renderer.cl:491)
   RM_DEV v3 shade(int id) {
     const Sample s = sample_init(id);
