@@ -13,8 +13,9 @@ are interleaved over the ranks and the tile accumulators are gathered on rank
 0 over RCCL -- the total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.  `value` = primary rays (= samples) per second
-of the whole job; `roofline` prices the dominant kernel (one RenderImage pass)
-against HBM bandwidth using the ALGORITHMIC bytes of that pass (DESIGN.md);
+of the whole job; `roofline` prices the dominant kernel (render_samples_kernel:
+all RenderImage passes of the frame in one launch) against HBM bandwidth using
+the ALGORITHMIC bytes of the reference algorithm for that launch (DESIGN.md);
 `cpu_baseline` is the CPU restatement of the reference kernel (oracle/) timed
 on this box's host cores on a bounded sample -- reported, not the target.
 """
@@ -79,7 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=2, help="passes of the workload the CPU baseline renders")
+    ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -133,9 +134,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # Dominant kernel: the RenderImage pass.  HIP events bracket the `spp` pass
-    # launches of a frame on the stream they run on; measured on extra frames
-    # right after the timed region so the event reads do not perturb it.
+    # Dominant kernel: render_samples_kernel.  HIP events bracket its launch(es) of a
+    # frame on the stream they run on (torch's current stream, handed to the library);
+    # measured on extra frames right after the timed region so the event reads do not
+    # perturb it.
     launches = 1
     for _ in range(5):
         fr.render()
@@ -182,7 +184,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "render_samples_kernel", "kernel_ms": round(pass_ms, 4),
+                "kernel": "render_samples_kernel<accel, 8 waves/SIMD>", "kernel_ms": round(pass_ms, 4),
                 "launches_per_frame": launches,
                 "alg_bytes_per_launch": int(alg_bytes_launch),
                 "alg_bytes_per_sample": round(alg_bytes_frame / samples_per_frame, 1),
@@ -190,6 +192,20 @@ def main():
                 "table_reads_per_sample": round(c["mc_reads"] / samples_per_frame, 2),
             },
         }
+        if world == 1:
+            # the same frame through the host-buffer boundary (rm_render_frame: tables +
+            # records up, float4 accumulator + ARGB back over PCIe) -- never `value`
+            hctx = _native.Context(local_rank)
+            hctx.set_volume(vox, vres)
+            hctx.render_frame(opts, mc, n)
+            th = time.perf_counter()
+            for _ in range(3):
+                hctx.render_frame(opts, mc, n)
+            host_ms = (time.perf_counter() - th) / 3 * 1e3
+            hctx.close()
+            out["host_boundary"] = {"ms_per_frame": round(host_ms, 3),
+                                    "Mrays_per_s": round(samples_per_frame / host_ms / 1e3, 2),
+                                    "note": "rm_render_frame with host buffers (PCIe-inclusive)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vox, opts, mc, n, spp, args.cpu_passes)
     fr.close()
