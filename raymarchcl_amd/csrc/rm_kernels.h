@@ -20,11 +20,13 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
                               Counters* d_counters);
-// all `iter` passes of a partition in one launch -> staging [iter][tiles_per_part*64] float4
+// all `iter` passes of a partition in one launch -> staging [iter][tiles_per_part*64] float4.
+// pp_log2 > 0: a wavefront holds 2^pp_log2 passes of 64/2^pp_log2 pixels -- only valid when the
+// `iter` records are identical except .time (reduced automatically until it divides iter).
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel accel,
                                  const float* d_mc_all, const RmOpts* d_opts_all, int resx, int iter,
                                  float* d_staging, int n, int tile_first, int tile_stride,
-                                 int min_waves = 3);
+                                 int min_waves, int pp_log2);
 // the same in two launches (march chain -> hit records in d_hits -> lighting);
 // d_hits: (1 + reflectIter) * iter * tiles_per_part * 64 * 32 bytes
 hipError_t launch_render_split(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,

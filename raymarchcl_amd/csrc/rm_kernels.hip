@@ -95,26 +95,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
 // per-pass tail (waves of the next pass fill the CUs while expensive tiles of
 // the previous one finish) and costs the same 32 B per sample the reference
 // spends on its read-modify-write of the accumulator.
+// Lane -> (pixel, pass).  With pp = 1 a wavefront is one 8x8 tile of one pass.
+// With pp = 2^k > 1 (possible when the passes' records differ only in .time) it
+// is a (64/pp)-pixel block of the tile times pp consecutive passes: lanes that
+// trace the SAME pixel with different jitter follow almost the same control flow,
+// which is what a 64-wide SIMT machine wants -- neighbouring pixels of one pass
+// diverge far more (sky / surface / reflection) than passes of one pixel.
 template <bool ACCEL, int MINW>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
     const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
-    int tile_stride, int tiles_per_part) {
-  const int pass = blockIdx.y;
-  const RmOpts* __restrict__ opts = opts_all + pass;
+    int tile_stride, int tiles_per_part, int pp_log2) {
+  const int pp = 1 << pp_log2;              // passes per wavefront
+  const int ppw = 64 >> pp_log2;            // pixels per wavefront
+  const int pass0 = blockIdx.y * pp;
+  const RmOpts* __restrict__ opts = opts_all + pass0;  // uniform record (pp > 1: all equal but .time)
   const int resx = opts->resolution[0];
   const TileGeom g = tile_geom(resx, n);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
+  // wavefronts of a tile are consecutive: tile slot = w / pp, sub-block = w % pp
+  const long long w = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long slot = w >> pp_log2;
+  const int sub = (int)(w & (pp - 1));
   const long long tile = tile_first + slot * tile_stride;
   if (tile >= g.tiles_total) return;
-  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, 0, n);
+  const int pass = pass0 + (lane & (pp - 1));
+  // Z-order inside the tile, so that any 2^k consecutive pixels form a compact block
+  const int z = sub * ppw + (lane >> pp_log2);
+  const int zx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+  const int zy = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+  const int pix = zy * 8 + zx;  // 0..63 within the tile, row-major 8x8
+  const int id = lane_pixel((int)tile, pix, resx, g.tiles_x, n, 0, n);
   if (id < 0) return;
-  rmk::Scene sc{vox, mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts, dist8, surf32};
+  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32};
   rmk::Tracer<false, ACCEL> tr(sc);
+  if (pp > 1) tr.set_pass(mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts_all[pass].time);
   const rmk::v3 col = tr.shade(id);
-  staging[((long long)pass * tiles_per_part + slot) * 64 + lane] = make_float4(col.x, col.y, col.z, 1.0f);
+  staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
 }
 
 // The two halves of a sample (Tracer::trace_chain / shade_from_hits): same grid
@@ -356,29 +374,31 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
 
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
                                  const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
-                                 int tile_first, int tile_stride, int min_waves) {
+                                 int tile_first, int tile_stride, int min_waves, int pp_log2) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
   const long long my_tiles =
       tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
   if (my_tiles == 0 || iter <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((my_tiles + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)iter);
+  while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;  // pass groups must tile `iter`
+  const long long waves = my_tiles << pp_log2;
+  const dim3 grid((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)(iter >> pp_log2));
   const dim3 block(64 * kWavesPerBlock);
   const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
   float4* st4 = reinterpret_cast<float4*>(staging);
   if (accel.dist && accel.surf)
     switch (min_waves) {
-      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
-      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
-      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
-      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
-      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
-      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp); break;
+      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
+      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
+      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
+      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
+      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
+      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
     }
   else
     render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
-                                                         n, tile_first, tile_stride, tpp);
+                                                         n, tile_first, tile_stride, tpp, pp_log2);
   return hipGetLastError();
 }
 

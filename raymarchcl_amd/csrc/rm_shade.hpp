@@ -204,6 +204,11 @@ template <bool COUNT, bool ACCEL = false>
 struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
   const Scene& sc;
+  // The pass a lane works on: its scatter table and its record's .time.  Defaults
+  // to the scene's (uniform); set_pass() makes them per-lane so that one wavefront
+  // can hold several passes of the same pixels (records equal except .time).
+  const float4* mc_;
+  float time_;
   Counters cnt;  // per-lane, only touched when COUNT
 #ifdef RM_WORK_STATS
   // debug build only: what the accelerated path actually executes
@@ -212,12 +217,16 @@ struct Tracer {
 #else
 #define RM_WS(x) ((void)0)
 #endif
-  RM_DEV explicit Tracer(const Scene& s) : sc(s), cnt{} {}
+  RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {}
+  RM_DEV void set_pass(const float4* table_of_pass, float time_of_pass) {
+    mc_ = table_of_pass;
+    time_ = time_of_pass;
+  }
 
   // scatter table lookup: renderer.cl:142-144
   RM_DEV float4 table(uint32_t seed) {
     if (COUNT) cnt.mc_reads++;
-    return sc.mc[seed & (RM_TABLE_ENTRIES - 1)];
+    return mc_[seed & (RM_TABLE_ENTRIES - 1)];
   }
 
   RM_DEV Material material(int id) {
@@ -532,11 +541,11 @@ struct Tracer {
   RM_DEV Sample sample_init(int id) {
     const RmOpts& o = *sc.o;
     Sample s;
-    s.time = o.time;
+    s.time = time_;
     const int resx = o.resolution[0];
     const float fx = (float)(id % resx), fy = (float)(id / resx);
-    const float4 mcPos = table((uint32_t)id * 17u + rmd::f2u(o.time * 3141.3862f));
-    const float4 t = table((uint32_t)id * 37u + rmd::f2u(o.time * 1859.1467f));
+    const float4 mcPos = table((uint32_t)id * 17u + rmd::f2u(time_ * 3141.3862f));
+    const float4 t = table((uint32_t)id * 37u + rmd::f2u(time_ * 1859.1467f));
     s.mcNormal = normalize(V(t.x, t.y, t.z));
     s.px = fx + mcPos.z;
     s.py = fy + mcPos.w;
