@@ -166,7 +166,8 @@ def main():
         achieved = alg_bytes_launch / (pass_ms * 1e-3) / 1e9
         traffic = load_traffic(args.traffic) if (world == 1 and args.workload == "c2") else None
         out = {
-            "metric": "Mrays/s (primary rays = pixel samples per second) + ms/frame, 256^3 gyroid 1280x720x16spp",
+            "metric": "Mrays/s (primary rays = pixel samples per second) + ms/frame, " +
+                      ("256^3 gyroid 1280x720x16spp" if args.workload == "c2" else wl["desc"]),
             "value": round(value, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
