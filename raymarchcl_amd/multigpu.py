@@ -72,6 +72,10 @@ def gather_tiles(local_tiles, rank, world, dst=0, group=None):
     import torch
     import torch.distributed as dist
 
+    if local_tiles.is_cuda and dist.get_backend(group) == "gloo":
+        # debugging / single-GPU test path: gloo cannot gather device tensors, stage via host
+        host = gather_tiles(local_tiles.cpu(), rank, world, dst=dst, group=group)
+        return host.to(local_tiles.device) if host is not None else None
     if rank == dst:
         out = torch.empty(world * local_tiles.numel(), dtype=local_tiles.dtype,
                           device=local_tiles.device)
