@@ -63,7 +63,12 @@ int rm_device_count(void);
 int rm_create(int device_id, rm_ctx** out);
 void rm_destroy(rm_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
- * the context's own stream; NULL restores the internal one. */
+ * the context's own non-blocking stream.  NULL is a valid handle: the legacy
+ * default stream (what torch uses unless told otherwise); RM_OWN_STREAM
+ * restores the internal one.  Work the caller enqueues around the calls
+ * (copies, RCCL collectives) is ordered with the kernels only if it uses the
+ * same stream. */
+#define RM_OWN_STREAM ((void*)(intptr_t)-1)
 int rm_set_stream(rm_ctx* ctx, void* hip_stream);
 int rm_synchronize(rm_ctx* ctx);
 

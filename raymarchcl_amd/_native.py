@@ -164,7 +164,9 @@ class Context:
         self.vres = (rx, ry, rz)
 
     def set_stream(self, stream_ptr):
-        check(lib().rm_set_stream(self._h, stream_ptr))
+        """hipStream_t handle as int; 0 = the legacy default stream (torch's default),
+        -1 = back to the context's own stream."""
+        check(lib().rm_set_stream(self._h, _vp(stream_ptr & 0xFFFFFFFFFFFFFFFF)))
 
     def synchronize(self):
         check(lib().rm_synchronize(self._h))

@@ -368,7 +368,7 @@ void rm_destroy(rm_ctx* c) {
 int rm_set_stream(rm_ctx* c, void* hip_stream) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = hip_stream == RM_OWN_STREAM ? c->own_stream : static_cast<hipStream_t>(hip_stream);
   return RM_OK;
 }
 
