@@ -73,6 +73,7 @@ struct rm_ctx {
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
   int split_mode = 0;      // RAYMARCH_KERNEL=split: march chain and lighting as two launches
   int split_tw = 8, split_lw = 8;  // RAYMARCH_SPLIT_WAVES=t,l
+  bool xcd_rows = true;    // RAYMARCH_XCD_ROWS=0: plain block order
   int pass_pack = 4;       // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds
   int straight_waves = 8;  // RAYMARCH_STRAIGHT_WAVES (3..8): waves/SIMD the register budget of
                            // render_samples_kernel leaves room for (8 = 64 VGPRs + scratch spills)
@@ -272,7 +273,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel,
                                          d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx,
                                          i1 - i0, staging + (size_t)i0 * count * 4, n, tile_first,
-                                         tile_stride, c->straight_waves, c->pass_pack));
+                                         tile_stride, c->straight_waves, c->pass_pack, c->xcd_rows));
     }
     launches++;
     i0 = i1;
@@ -334,6 +335,8 @@ int rm_create(int device_id, rm_ctx** out) {
   c->split_mode = km && strcmp(km, "split") == 0;
   const char* spw = getenv("RAYMARCH_SPLIT_WAVES");
   if (spw) sscanf(spw, "%d,%d", &c->split_tw, &c->split_lw);
+  const char* xr = getenv("RAYMARCH_XCD_ROWS");
+  if (xr) c->xcd_rows = xr[0] != '0';
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) c->pass_pack = atoi(pk);
   const char* sw = getenv("RAYMARCH_STRAIGHT_WAVES");

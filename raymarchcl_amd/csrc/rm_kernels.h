@@ -26,7 +26,7 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* d_vox, Accel accel,
                                  const float* d_mc_all, const RmOpts* d_opts_all, int resx, int iter,
                                  float* d_staging, int n, int tile_first, int tile_stride,
-                                 int min_waves, int pp_log2);
+                                 int min_waves, int pp_log2, bool xcd_rows);
 // the same in two launches (march chain -> hit records in d_hits -> lighting);
 // d_hits: (1 + reflectIter) * iter * tiles_per_part * 64 * 32 bytes
 hipError_t launch_render_split(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,

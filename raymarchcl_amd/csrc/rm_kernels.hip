@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
     const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
-    int tile_stride, int tiles_per_part, int pp_log2) {
+    int tile_stride, int tiles_per_part, int pp_log2, int bpr) {
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
   const int pass0 = blockIdx.y * pp;
@@ -114,8 +114,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   const int resx = opts->resolution[0];
   const TileGeom g = tile_geom(resx, n);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // XCD-aware order (bpr > 0): the dispatcher deals consecutive workgroups to the 8
+  // XCDs round-robin, each with its own L2.  Hardware block b = 8*m + k is given the
+  // logical block of tile row 8*(m / bpr) + k, so XCD k renders every 8th tile ROW:
+  // its primary rays sweep an eighth of the volume's slabs instead of all of them,
+  // while rows stay interleaved finely enough to balance the load.
+  long long lb = blockIdx.x;
+  if (bpr > 0) {
+    const long long m = lb >> 3, k = lb & 7;
+    lb = ((m / bpr) * 8 + k) * bpr + (m % bpr);
+  }
   // wavefronts of a tile are consecutive: tile slot = w / pp, sub-block = w % pp
-  const long long w = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long w = lb * kWavesPerBlock + wave;
   const long long slot = w >> pp_log2;
   const int sub = (int)(w & (pp - 1));
   const long long tile = tile_first + slot * tile_stride;
@@ -374,7 +384,8 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
 
 hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
                                  const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
-                                 int tile_first, int tile_stride, int min_waves, int pp_log2) {
+                                 int tile_first, int tile_stride, int min_waves, int pp_log2,
+                                 bool xcd_rows) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
@@ -383,22 +394,31 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
   if (my_tiles == 0 || iter <= 0) return hipSuccess;
   while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;  // pass groups must tile `iter`
   const long long waves = my_tiles << pp_log2;
-  const dim3 grid((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)(iter >> pp_log2));
+  long long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  // blocks per tile row, for the XCD-aware order (whole image on this device only)
+  int bpr = 0;
+  if (xcd_rows && tile_stride == 1 && tile_first == 0 &&
+      ((long long)g.tiles_x << pp_log2) % kWavesPerBlock == 0) {
+    bpr = (int)(((long long)g.tiles_x << pp_log2) / kWavesPerBlock);
+    const long long rows = (blocks + bpr - 1) / bpr;
+    blocks = ((rows + 7) / 8) * 8 * bpr;  // pad to groups of 8 rows; surplus blocks exit at once
+  }
+  const dim3 grid((unsigned)blocks, (unsigned)(iter >> pp_log2));
   const dim3 block(64 * kWavesPerBlock);
   const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
   float4* st4 = reinterpret_cast<float4*>(staging);
   if (accel.dist && accel.surf)
     switch (min_waves) {
-      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
-      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
-      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
-      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
-      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
-      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2); break;
+      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
+      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
+      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
+      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
+      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
+      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
     }
   else
     render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
-                                                         n, tile_first, tile_stride, tpp, pp_log2);
+                                                         n, tile_first, tile_stride, tpp, pp_log2, bpr);
   return hipGetLastError();
 }
 
