@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libraymarch_hip.so")
 SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_stream.hip", "rm_api.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 OPTS_BYTES = 544
 TABLE_FLOATS = 0x4000 * 4
