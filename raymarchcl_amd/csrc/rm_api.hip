@@ -71,6 +71,7 @@ struct rm_ctx {
   DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
+  int phase_mode = 0;      // RAYMARCH_KERNEL=phases: chain / point rays / shading as three launches
   int split_mode = 0;      // RAYMARCH_KERNEL=split: march chain and lighting as two launches
   int split_tw = 8, split_lw = 8;  // RAYMARCH_SPLIT_WAVES=t,l
   bool xcd_rows = true;    // RAYMARCH_XCD_ROWS=0: plain block order
@@ -209,7 +210,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
   for (int i0 = 0; i0 < iter;) {
     int i1 = i0 + 1;
     const bool wave = c->wave_mode && c->use_accel;
-    const bool need_same = wave || c->pass_pack > 0;  // launches whose lanes share one record
+    const bool need_same = wave || c->pass_pack > 0 || c->phase_mode;  // launches whose lanes share one record
     while (i1 < iter && iso_per_pass[i1] == iso_per_pass[i0] && (!need_same || same_as_prev[i1])) i1++;
     rmk::Accel accel;
     int rc = ensure_accel(c, iso_per_pass[i0], &accel);
@@ -248,6 +249,17 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
         }
         j0 = j1;
       }
+      i0 = i1;
+      continue;
+    }
+    if (c->phase_mode && c->use_accel) {
+      const int levels = 1 + (h0.reflectIter > 0 ? h0.reflectIter : 0);
+      HIP_TRY(c->work_buf.reserve(rmk::phases_workspace_bytes((size_t)(i1 - i0) * count, levels)));
+      HIP_TRY(rmk::launch_render_phases(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
+                                        d_opts + i0, resx, i1 - i0, levels,
+                                        staging + (size_t)i0 * count * 4, c->work_buf.p, n, tile_first,
+                                        tile_stride, c->pass_pack));
+      launches++;
       i0 = i1;
       continue;
     }
@@ -333,6 +345,7 @@ int rm_create(int device_id, rm_ctx** out) {
   c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
   c->stream_mode = km && strcmp(km, "stream") == 0;  // experimental task-queue pipeline
   c->split_mode = km && strcmp(km, "split") == 0;
+  c->phase_mode = km && strcmp(km, "phases") == 0;
   const char* spw = getenv("RAYMARCH_SPLIT_WAVES");
   if (spw) sscanf(spw, "%d,%d", &c->split_tw, &c->split_lw);
   const char* xr = getenv("RAYMARCH_XCD_ROWS");

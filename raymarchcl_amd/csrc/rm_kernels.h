@@ -33,6 +33,14 @@ hipError_t launch_render_split(hipStream_t st, const uint8_t* d_vox, Accel accel
                                const RmOpts* d_opts_all, int resx, int iter, float* d_staging,
                                float* d_hits, int n, int tile_first, int tile_stride, int waves_trace,
                                int waves_light);
+// the same in three launches: march chain -> hit records; the rays of every shaded point
+// (AO loop + shadow marches) -> one float + light bits; shading arithmetic -> staging.
+// d_work: phases_workspace_bytes(iter * tiles_per_part * 64, levels) bytes.
+size_t phases_workspace_bytes(size_t samples, int levels);
+hipError_t launch_render_phases(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,
+                                const RmOpts* d_opts_all, int resx, int iter, int levels,
+                                float* d_staging, void* d_work, int n, int tile_first,
+                                int tile_stride, int pp_log2);
 // the same, by the persistent wave-scheduled kernel (needs the accel structures and
 // option records that differ only in .time); d_queue: one device uint32 of scratch
 hipError_t launch_render_wave(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc_all,

@@ -193,6 +193,74 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void light_kernel(
   staging[sidx] = make_float4(col.x, col.y, col.z, 1.0f);
 }
 
+// Three-phase form (Tracer::trace_chain / point_rays / shade_from_rays).  All three use
+// the pass-packed lane mapping of render_samples_kernel; phase 2 has a z dimension
+// over the shading levels (0 = primary hit, k = reflection k).
+struct LaneMap { int id, pass; long long sidx; };
+__device__ __forceinline__ LaneMap lane_map(const RmOpts* opts_all, int n, int tile_first, int tile_stride,
+                                            int tiles_per_part, int pp_log2) {
+  LaneMap r;
+  r.id = -1;
+  const int pp = 1 << pp_log2, ppw = 64 >> pp_log2;
+  const int pass0 = blockIdx.y * pp;
+  const int resx = opts_all[pass0].resolution[0];
+  const TileGeom g = tile_geom(resx, n);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * kWavesPerBlock + wave;
+  const long long slot = w >> pp_log2;
+  const int sub = (int)(w & (pp - 1));
+  const long long tile = tile_first + slot * tile_stride;
+  r.pass = pass0 + (lane & (pp - 1));
+  r.sidx = 0;
+  if (tile >= g.tiles_total) return r;
+  const int z = sub * ppw + (lane >> pp_log2);
+  const int zx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+  const int zy = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+  const int pix = zy * 8 + zx;
+  r.id = lane_pixel((int)tile, pix, resx, g.tiles_x, n, 0, n);
+  r.sidx = ((long long)r.pass * tiles_per_part + slot) * 64 + pix;
+  return r;
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 8) void phase_kernel(
+    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
+    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
+    const RmOpts* __restrict__ opts_all, float4* __restrict__ hits, float2* __restrict__ rays,
+    float4* __restrict__ staging, int n, int tile_first, int tile_stride, int tiles_per_part,
+    int pp_log2, int iter) {
+  const LaneMap lm = lane_map(opts_all, n, tile_first, tile_stride, tiles_per_part, pp_log2);
+  if (lm.id < 0) return;
+  const int pass0 = blockIdx.y << pp_log2;
+  const RmOpts* __restrict__ opts = opts_all + pass0;
+  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32};
+  rmk::Tracer<false, true> tr(sc);
+  if (pp_log2 > 0) tr.set_pass(mc_all + (size_t)lm.pass * RM_TABLE_ENTRIES, opts_all[lm.pass].time);
+  const size_t samples = (size_t)iter * tiles_per_part * 64;
+  if (PHASE == 1) {
+    tr.trace_chain(lm.id, hits, samples, (size_t)lm.sidx);
+  } else if (PHASE == 2) {
+    const int level = blockIdx.z;
+    const float4* h = hits + ((size_t)level * samples + lm.sidx) * 2;
+    const float4 ha = h[0], hb = h[1];
+    const int obj = __float_as_int(hb.w);
+    rmk::v3 nrm = rmk::V(hb.x, hb.y, hb.z);
+    if (level == 0) {
+      if (ha.w >= opts->maxDist) return;  // primary miss
+      const rmk::Material m = rmk::material_of(*opts, obj);
+      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      nrm = rmk::mads(tr.sample_mc_normal(lm.id), k, nrm);  // renderer.cl:420
+    } else if (obj < 0) {
+      return;  // no such bounce / it left the scene
+    }
+    const auto s = tr.sample_seeds(lm.id);
+    rays[(size_t)level * samples + lm.sidx] = tr.point_rays(s, rmk::V(ha.x, ha.y, ha.z), nrm);
+  } else {
+    const rmk::v3 col = tr.shade_from_rays(lm.id, hits, rays, samples, (size_t)lm.sidx);
+    staging[lm.sidx] = make_float4(col.x, col.y, col.z, 1.0f);
+  }
+}
+
 // Persistent, wave-scheduled renderer (rm_wave.hpp): each wavefront pulls tiles
 // from a queue, keeps a pool of (pixel, pass) samples of its tile, and
 // alternates between one shared march loop and short per-lane continuations.
@@ -455,6 +523,38 @@ hipError_t launch_render_split(hipStream_t st, const uint8_t* vox, Accel accel, 
 #undef RM_L
   return hipGetLastError();
 }
+
+hipError_t launch_render_phases(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
+                                const RmOpts* d_opts_all, int resx, int iter, int levels,
+                                float* staging, void* work, int n, int tile_first, int tile_stride,
+                                int pp_log2) {
+  const TileGeom g = tile_geom(resx, n);
+  if (tile_stride < 1) tile_stride = 1;
+  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
+  const long long my_tiles =
+      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
+  if (my_tiles == 0 || iter <= 0) return hipSuccess;
+  while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;
+  const long long waves = my_tiles << pp_log2;
+  const unsigned bx = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+  const unsigned by = (unsigned)(iter >> pp_log2);
+  const dim3 block(64 * kWavesPerBlock);
+  const size_t samples = (size_t)iter * tpp * 64;
+  float4* hits = static_cast<float4*>(work);
+  float2* rays = reinterpret_cast<float2*>(hits + samples * levels * 2);
+  const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
+  float4* st4 = reinterpret_cast<float4*>(staging);
+  phase_kernel<1><<<dim3(bx, by, 1), block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, hits, rays,
+                                                      st4, n, tile_first, tile_stride, tpp, pp_log2, iter);
+  phase_kernel<2><<<dim3(bx, by, (unsigned)levels), block, 0, st>>>(vox, accel.dist, accel.surf, mc4,
+                                                                     d_opts_all, hits, rays, st4, n,
+                                                                     tile_first, tile_stride, tpp,
+                                                                     pp_log2, iter);
+  phase_kernel<3><<<dim3(bx, by, 1), block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, hits, rays,
+                                                      st4, n, tile_first, tile_stride, tpp, pp_log2, iter);
+  return hipGetLastError();
+}
+size_t phases_workspace_bytes(size_t samples, int levels) { return samples * levels * (32 + 8) + 256; }
 
 hipError_t launch_render_wave(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
                               const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,

@@ -580,6 +580,9 @@ struct Tracer {
     march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
     hits[sidx * 2] = make_float4(h.pos.x, h.pos.y, h.pos.z, h.distance);
     hits[sidx * 2 + 1] = make_float4(h.normal.x, h.normal.y, h.normal.z, __int_as_float(h.objectID));
+    // the record after the last traced level says "no such bounce" (objectID -1)
+    float4* const nxt = hits + (samples + sidx) * 2 + 1;
+    if (o.reflectIter > 0) *nxt = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     if (h.distance >= o.maxDist) return;
     const Material m = material(h.objectID);
     if (!(m.r0 > 0.0f && o.reflectIter > 0)) return;
@@ -595,6 +598,7 @@ struct Tracer {
       float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
       hk[0] = make_float4(rh.pos.x, rh.pos.y, rh.pos.z, rh.distance);
       hk[1] = make_float4(rh.normal.x, rh.normal.y, rh.normal.z, __int_as_float(rh.objectID));
+      if (i + 1 < o.reflectIter) hk[samples * 2 + 1] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
       if (rh.objectID < 0) break;
       if ((double)material(rh.objectID).r0 < 0.001) break;
     }
@@ -638,6 +642,122 @@ struct Tracer {
         refl = sky(reflect(rdir, norm));
       }
       col = lighting(s, rdir, hpos, m, norm, refl);
+    }
+    return atmosphere(s, s.eye, rdir, hdist, col) * o.exposure;
+  }
+
+  // ---- three-phase form: (1) trace_chain, (2) the RAYS of each shaded point --
+  // its AO loop and one shadow march per light -- reduced to one float and one bit
+  // per light, (3) all shading arithmetic from those.  No phase holds another
+  // phase's state, so each compiles to <= 64 VGPRs without scratch traffic.
+  // Per-sample seeds without the camera (phase 2 needs no ray direction).
+  RM_DEV Sample sample_seeds(int id) {
+    const RmOpts& o = *sc.o;
+    Sample s;
+    s.time = time_;
+    const int resx = o.resolution[0];
+    const float4 mcPos = table((uint32_t)id * 17u + rmd::f2u(time_ * 3141.3862f));
+    s.px = (float)(id % resx) + mcPos.z;
+    s.py = (float)(id / resx) + mcPos.w;
+    s.mcNormal = V(0.f, 0.f, 0.f);
+    s.eye = s.mcNormal;
+    return s;
+  }
+  RM_DEV v3 sample_mc_normal(int id) {  // renderer.cl:472
+    const float4 t = table((uint32_t)id * 37u + rmd::f2u(time_ * 1859.1467f));
+    return normalize(V(t.x, t.y, t.z));
+  }
+  // phase 2: renderer.cl:327-346 and the shadow() calls of :361-369 for one point.
+  // -> (ao, bit i = shadow factor of light i, which is 0 or 1: renderer.cl:300)
+  RM_DEV float2 point_rays(const Sample& s, v3 pos, v3 normal) {
+    const RmOpts& o = *sc.o;
+    const float ao = occlusion(s, pos, normal);
+    unsigned bits = 0;
+    const int nl = o.numLights;
+    for (int i = 0; i < nl; i++) {
+      const v3 dl = light_at(s, i) - pos;
+      const float d2 = dot(dl, dl);
+      const float att = 1.0f / d2;
+      if (att > o.minLightAtt) {
+        const v3 ldir = normalize(dl);
+        const float sh = shadow_term(mads(ldir, o.shadowBias, pos), ldir,
+                                     rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist));
+        if (sh > 0.0f) bits |= 1u << i;
+      }
+    }
+    return make_float2(ao, __uint_as_float(bits));
+  }
+  // phase 3: lighting() with the rays' outcomes supplied (same arithmetic, same order)
+  RM_DEV v3 lighting_math(const Sample& s, v3 raydir, v3 hitpos, const Material& m, v3 normal,
+                          v3 reflectCol, float ao, unsigned bits) {
+    const RmOpts& o = *sc.o;
+    v3 diff = sky(normal) * ao;
+    v3 spec = reflectCol * ao;
+    v3 out = V(0.f, 0.f, 0.f);
+    const int nl = o.numLights;
+    for (int i = 0; i < nl; i++) {
+      const v3 dl = light_at(s, i) - hitpos;
+      const float d2 = dot(dl, dl);
+      const float att = 1.0f / d2;
+      if (att > o.minLightAtt) {
+        const v3 ldir = normalize(dl);
+        const float sh = (bits >> i) & 1u ? 1.0f : 0.0f;
+        if (sh > 0.0f) {
+          const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
+          diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+          spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+        }
+      }
+      diff = diff * m.albedo;
+      out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
+    }
+    const float fl = (float)nl;
+    return V(out.x / fl, out.y / fl, out.z / fl);
+  }
+  // phase 3 for one sample; rays: [level][samples] float2 from point_rays
+  RM_DEV v3 shade_from_rays(int id, const float4* __restrict__ hits, const float2* __restrict__ rays,
+                            size_t samples, size_t sidx) {
+    const RmOpts& o = *sc.o;
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    const float4 ha = hits[sidx * 2], hb = hits[sidx * 2 + 1];
+    const float hdist = ha.w;
+    v3 col;
+    if (hdist >= o.maxDist) {
+      col = sky(rdir);
+    } else {
+      const v3 hpos = V(ha.x, ha.y, ha.z);
+      const Material m = material(__float_as_int(hb.w));
+      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      const v3 norm = mads(s.mcNormal, k, V(hb.x, hb.y, hb.z));
+      v3 refl = V(0.f, 0.f, 0.f);
+      if (m.r0 > 0.0f && o.reflectIter > 0) {
+        v3 lpos = hpos, lnrm = norm, dir = rdir;
+        for (int i = 0; i < o.reflectIter; i++) {
+          dir = reflect(dir, lnrm);
+          const v3 from = mads(dir, 0.0075f, lpos);
+          const float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
+          const float4 ka = hk[0], kb = hk[1];
+          const int obj = __float_as_int(kb.w);
+          lpos = V(ka.x, ka.y, ka.z);
+          lnrm = V(kb.x, kb.y, kb.z);
+          v3 bc;
+          if (obj < 0) {
+            bc = sky(dir);
+          } else {
+            const float2 rr = rays[(size_t)(1 + i) * samples + sidx];
+            bc = lighting_math(s, dir, lpos, material(obj), lnrm, sky(reflect(dir, lnrm)), rr.x,
+                               __float_as_uint(rr.y));
+          }
+          refl = refl + atmosphere(s, from, dir, ka.w, bc);
+          if (obj < 0) break;
+          if ((double)material(obj).r0 < 0.001) break;
+        }
+      } else {
+        refl = sky(reflect(rdir, norm));
+      }
+      const float2 r0 = rays[sidx];
+      col = lighting_math(s, rdir, hpos, m, norm, refl, r0.x, __float_as_uint(r0.y));
     }
     return atmosphere(s, s.eye, rdir, hdist, col) * o.exposure;
   }

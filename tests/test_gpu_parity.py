@@ -192,6 +192,7 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
                 {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "2"},
                 {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVES": "4"}, {"RAYMARCH_KERNEL": "stream"},
                 {"RAYMARCH_PASS_PACK": "0"}, {"RAYMARCH_PASS_PACK": "1"}, {"RAYMARCH_PASS_PACK": "6"},
+                {"RAYMARCH_KERNEL": "phases"}, {"RAYMARCH_KERNEL": "phases", "RAYMARCH_PASS_PACK": "0"},
                 {"RAYMARCH_KERNEL": "split"}, {"RAYMARCH_KERNEL": "split", "RAYMARCH_SPLIT_WAVES": "4,5"},
                 {"RAYMARCH_KERNEL": "straight", "RAYMARCH_STRAIGHT_WAVES": "3"},
                 {"RAYMARCH_KERNEL": "straight", "RAYMARCH_STRAIGHT_WAVES": "5"},
