@@ -42,6 +42,8 @@ WORKLOADS = {
                vol="blobs", vres=512, w=1920, h=1080, spp=16, mat="metal"),
     "c4": dict(desc="256^3 gyroid, 3840x2160, 64 spp + DOF 0.025, :orange-stripes", vol="gyroid",
                vres=256, w=3840, h=2160, spp=64, mat="orange-stripes", dof=0.025),
+    "c5": dict(desc="1024^3 gyroid (dragon stand-in, generated on the device), 1920x1080, 25 spp, :metal",
+               vol="gyroid-gpu", vres=1024, w=1920, h=1080, spp=25, mat="metal"),
 }
 
 
@@ -51,7 +53,15 @@ def build_inputs(wl):
     from raymarchcl_amd import structs
 
     vres = wl["vres"]
-    vox = gen.make_gyroid_volume(vres) if wl["vol"] == "gyroid" else gen.make_blob_volume(vres)
+    if wl["vol"] == "gyroid":
+        vox = gen.make_gyroid_volume(vres)
+    elif wl["vol"] == "gyroid-gpu":
+        from raymarchcl_amd import _native
+
+        with _native.Context(int(os.environ.get("LOCAL_RANK", "0"))) as gctx:
+            vox = gctx.make_gyroid_volume(vres)
+    else:
+        vox = gen.make_blob_volume(vres)
     extra = {k: wl[k] for k in ("dof",) if k in wl}
     opts = b"".join(
         structs.encode_bytes(rm.render_options(

@@ -80,6 +80,12 @@ int rm_set_volume(rm_ctx* ctx, const uint8_t* voxels, int rx, int ry, int rz);
  * (borrowed until the next rm_set_volume* / rm_destroy). */
 int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int rz);
 
+/* gen/make-gyroid-volume (generators.clj:27-42) evaluated on the device: fills the
+ * context's resident volume (as rm_set_volume would) and, if voxels_out is not
+ * NULL, copies the rx*ry*rz bytes back.  The reference generates this grid on the
+ * host in minutes for 512^3; here it takes milliseconds. */
+int rm_make_gyroid_volume(rm_ctx* ctx, int rx, int ry, int rz, uint8_t* voxels_out);
+
 /* One NDRange of the RenderImage kernel (renderer.cl:478-494; pipeline step
  * core.clj:84-89): write opts + table, run work-items 0..n-1, read the
  * accumulator back.  `pixels` is in/out (n float4). */

@@ -1,0 +1,63 @@
+"""Command line front end for the render path.
+
+    python -m raymarchcl_amd gen-gyroid --res 256 --out gyroid-256.vox
+    python -m raymarchcl_amd render --vox gyroid-256.vox --mat metal --width 1280 --height 720 \\
+        --iter 16 --theta 135 --dist 2.25 --out frame.png
+
+`render` mirrors the reference's test-render (core.clj:154-179): same defaults,
+same parameter names.  Needs the HIP library and an MI355X (no CPU fallback).
+"""
+import argparse
+import sys
+import time
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m raymarchcl_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    g = sub.add_parser("gen-gyroid", help="write the gyroid benchmark volume as a .vox file")
+    g.add_argument("--res", type=int, default=256)
+    g.add_argument("--out", required=True)
+    g.add_argument("--cpu", action="store_true", help="generate with numpy instead of the device kernel")
+    r = sub.add_parser("render", help="render one frame of a .vox volume to a PNG (test-render)")
+    r.add_argument("--vox", required=True)
+    r.add_argument("--out", default="foo.png")
+    r.add_argument("--width", type=int, default=640)
+    r.add_argument("--height", type=int, default=360)
+    r.add_argument("--iter", type=int, default=1)
+    r.add_argument("--mat", default="metal")
+    r.add_argument("--theta", type=float, default=135)
+    r.add_argument("--dist", type=float, default=2.25)
+    r.add_argument("--dof", type=float, default=None)
+    r.add_argument("--fov", type=float, default=None)
+    r.add_argument("--gamma", type=float, default=None)
+    r.add_argument("--seed", type=int, default=1000, help="seed of the scatter tables")
+    r.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    from . import core, generators, vio
+
+    if args.cmd == "gen-gyroid":
+        t0 = time.time()
+        if args.cpu:
+            vox = generators.make_gyroid_volume(args.res)
+        else:
+            from . import _native
+
+            with _native.Context(0) as ctx:
+                vox = ctx.make_gyroid_volume(args.res)
+        vio.save_volume(args.out, args.res, vox)
+        print(f"{args.out}: {args.res}^3, {int((vox > 0).sum())} filled voxels, {time.time() - t0:.2f} s")
+        return 0
+    vox, vres = vio.load_volume(args.vox)
+    extra = {k: getattr(args, k) for k in ("dof", "fov", "gamma") if getattr(args, k) is not None}
+    t0 = time.time()
+    core.test_render(width=args.width, height=args.height, iter=args.iter, vres=list(vres), mat=args.mat,
+                     theta=args.theta, dist=args.dist, voxels=vox, out_path=args.out, mc_seed=args.seed,
+                     device=args.device, **extra)
+    print(f"{args.out}: {args.width}x{args.height}, {args.iter} spp, {time.time() - t0:.2f} s")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -23,6 +23,7 @@ TABLE_FLOATS = 0x4000 * 4
 EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_destroy",
     "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_make_gyroid_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_selftest_prims",
@@ -96,6 +97,7 @@ def lib():
     L.rm_synchronize.argtypes = [_vp]
     L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
+    L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
     L.rm_render_image.argtypes = [_vp, _vp, _vp, _vp, _i]
     L.rm_render_image_range.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i]
     L.rm_render_image_counted.argtypes = [_vp, _vp, _vp, _vp, _i, ctypes.POINTER(Counters)]
@@ -162,6 +164,15 @@ class Context:
         rx, ry, rz = (int(v) for v in vres)
         check(lib().rm_set_volume_device(self._h, dptr, rx, ry, rz))
         self.vres = (rx, ry, rz)
+
+    def make_gyroid_volume(self, vres, want_host_copy=True):
+        """Generate the gyroid benchmark volume on the device; it becomes the resident
+        volume.  Returns the bytes (uint8) when want_host_copy."""
+        rx, ry, rz = ((int(vres),) * 3 if isinstance(vres, (int, np.integer)) else tuple(int(v) for v in vres))
+        out = np.zeros(rx * ry * rz, dtype=np.uint8) if want_host_copy else None
+        check(lib().rm_make_gyroid_volume(self._h, rx, ry, rz, out.ctypes.data if want_host_copy else None))
+        self.vres = (rx, ry, rz)
+        return out
 
     def set_stream(self, stream_ptr):
         """hipStream_t handle as int; 0 = the legacy default stream (torch's default),

@@ -108,9 +108,39 @@ __global__ __launch_bounds__(256) void surf_kernel(const uint8_t* __restrict__ v
   }
 }
 
+// The benchmark volume on the device (reference generators.clj:18-42 fills it on one
+// JVM thread, minutes for 512^3).  Same formula in binary64; cos/sin come from the
+// device math library, so a voxel whose value sits within an ulp of a threshold may
+// differ from a host-generated grid -- the grid is an INPUT of the render path, parity
+// tests always feed both sides the same bytes.
+__global__ __launch_bounds__(256) void gyroid_kernel(uint8_t* __restrict__ out, Dim d) {
+  const long long total = (long long)d.rx * d.ry * d.rz;
+  const double scl = 0.01 * (512.0 / (double)d.rx);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % d.rx), y = (int)((i / d.rx) % d.ry), z = (int)(i / ((long long)d.rx * d.ry));
+    uint8_t b = 0;
+    if ((z & 0x3f) >= 32) {
+      const double X = (double)x * scl + 0.3875, Y = (double)y * scl + 0.0, Z = (double)z * scl + 0.0;
+      const double v = fabs(cos(X) * sin(Z) + cos(Y) * sin(X) + cos(Z) * sin(Y)) - 1.0;
+      if (fabs(0.2 - v) < 0.05) b = (x & 0x3f) < 32 ? 64 : 128;
+      else if (v > 0.35) b = 255;
+    }
+    out[i] = b;
+  }
+}
+
 }  // namespace
 
 namespace rmk {
+
+hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz) {
+  const Dim d{rx, ry, rz};
+  const long long total = (long long)rx * ry * rz;
+  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  gyroid_kernel<<<blocks, 256, 0, st>>>(d_out, d);
+  return hipGetLastError();
+}
 
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                        uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf) {

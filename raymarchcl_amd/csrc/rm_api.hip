@@ -431,6 +431,23 @@ int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz
   return RM_OK;
 }
 
+int rm_make_gyroid_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  rc = check_res(rx, ry, rz);
+  if (rc) return rc;
+  const size_t bytes = (size_t)rx * ry * rz;
+  HIP_TRY(c->vox_buf.reserve(bytes));
+  HIP_TRY(rmk::launch_gyroid(c->stream, static_cast<uint8_t*>(c->vox_buf.p), rx, ry, rz));
+  if (voxels_out)
+    HIP_TRY(hipMemcpyAsync(voxels_out, c->vox_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
+  c->rx = rx; c->ry = ry; c->rz = rz;
+  c->accel_iso = -1;
+  return RM_OK;
+}
+
 int rm_render_image(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n) {
   return render_pass_host(c, mc, opts544, pixels, n, 0, n, nullptr);
 }

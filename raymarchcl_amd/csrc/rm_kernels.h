@@ -60,6 +60,7 @@ hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d
 // d_tmp is scratch of the volume's size.
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                        uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf);
+hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,
                         int n);
 }  // namespace rmk

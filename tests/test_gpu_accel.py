@@ -50,3 +50,21 @@ def test_dist8_and_surf32(gpu_ctx, kind, vres, iso):
     assert np.array_equal(((s >> 26) & 3).astype(np.int32)[hit] - 1, gx[c][hit])
     assert np.array_equal(((s >> 28) & 3).astype(np.int32)[hit] - 1, gy[c][hit])
     assert np.array_equal(((s >> 30) & 3).astype(np.int32)[hit] - 1, gz[c][hit])
+
+
+def test_device_gyroid_generator_matches_host(native):
+    """rm_make_gyroid_volume == generators.make_gyroid_volume up to voxels whose value
+    lies within rounding of a threshold (device vs host cos/sin)."""
+    from raymarchcl_amd import generators
+
+    with native.Context(0) as ctx:
+        for res in (64, (96, 64, 128)):
+            got = ctx.make_gyroid_volume(res)
+            want = generators.make_gyroid_volume(res)
+            assert got.shape == want.shape and set(np.unique(got)) <= {0, 64, 128, 255}
+            assert (got != want).mean() < 1e-5
+        # it is the resident volume now: rendering works without rm_set_volume
+        sc = scenes.build("c1_orange")
+        ctx.make_gyroid_volume(64, want_host_copy=False)
+        px, _ = ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+        assert np.isfinite(px).all() and px.any()
