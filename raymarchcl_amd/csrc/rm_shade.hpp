@@ -68,18 +68,21 @@ struct Scene {
 // second, and jumps the remaining k-2 samples in one step -- provided start,
 // warm-up and landing points share their binade component-wise; otherwise it
 // reports failure and the caller falls back to single adds.
-RM_DEV bool same_binade(float a, float b) {
-  return ((__float_as_uint(a) ^ __float_as_uint(b)) & 0xff800000u) == 0u;  // sign + exponent
-}
+// (straight-line on purpose: a short-circuit chain of six comparisons compiles to
+//  six nested exec-mask branches on this target)
 RM_DEV bool advance_exact(v3& p, v3 delta, int k) {
   const v3 p1 = p + delta;
   const v3 p2 = p1 + delta;
   const v3 D = p2 - p1;
   const float m = (float)(k - 2);
   const v3 q = V(p2.x + m * D.x, p2.y + m * D.y, p2.z + m * D.z);
-  const bool ok = same_binade(p.x, p2.x) && same_binade(p.y, p2.y) && same_binade(p.z, p2.z) &&
-                  same_binade(p.x, q.x) && same_binade(p.y, q.y) && same_binade(p.z, q.z);
-  if (ok) p = q;
+  // sign + exponent of start, warm-up and landing point must agree per component
+  const uint32_t px = __float_as_uint(p.x), py = __float_as_uint(p.y), pz = __float_as_uint(p.z);
+  const uint32_t diff = (px ^ __float_as_uint(p2.x)) | (py ^ __float_as_uint(p2.y)) |
+                        (pz ^ __float_as_uint(p2.z)) | (px ^ __float_as_uint(q.x)) |
+                        (py ^ __float_as_uint(q.y)) | (pz ^ __float_as_uint(q.z));
+  const bool ok = (diff & 0xff800000u) == 0u;
+  p = V(ok ? q.x : p.x, ok ? q.y : p.y, ok ? q.z : p.z);
   return ok;
 }
 
@@ -114,8 +117,8 @@ RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
   return b > a ? a : -1.0f;
 }
 RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {  // 0 <= q < res per axis
-  return (unsigned)qz < (unsigned)o.voxelRes[2] && (unsigned)qy < (unsigned)o.voxelRes[1] &&
-         (unsigned)qx < (unsigned)o.voxelRes[0];
+  return ((unsigned)qz < (unsigned)o.voxelRes[2]) & ((unsigned)qy < (unsigned)o.voxelRes[1]) &
+         ((unsigned)qx < (unsigned)o.voxelRes[0]);
 }
 // renderer.cl:259-261
 RM_DEV v3 sky_of(const RmOpts& o, v3 dir) {
@@ -168,35 +171,31 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // cell of accumulated rounding drift and the rounding of p*res).
 RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
                      float inv_s, int* cell_out) {
-  if (steps <= 0) return 2;
   const int qx = rmd::convert_int_sat(p.x * (float)o.voxelRes[0]);
   const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
   const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
-  if (!in_grid_of(o, qx, qy, qz)) return 2;  // renderer.cl:221
+  if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
   const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
   const int d = dist8[cell];
   if (d == 0) {
     *cell_out = cell;
     return 1;
   }
-  int j = 1 + (int)((float)(d - 1) * inv_s);
   // (the floor argument above needs p >= 0; tiny p also means tiny binades)
-  if (j >= 2 && fminf(fminf(p.x, p.y), p.z) >= 0.015625f) {
-    if (j >= steps) return 2;
-    if (j >= 8) {
-      if (advance_exact(p, delta, j)) {
-        steps -= j;
-        return 0;
-      }
-      j >>= 2;
+  const bool roomy = fminf(fminf(p.x, p.y), p.z) >= 0.015625f;
+  int j = roomy ? 1 + (int)((float)(d - 1) * inv_s) : 1;
+  if (j >= steps) return 2;  // no sample left that could hit anything
+  if (j >= 8) {
+    if (advance_exact(p, delta, j)) {
+      steps -= j;
+      return 0;
     }
-    const int jj = j > 7 ? 7 : j;  // short skips: the reference's own adds, no fetches
-    for (int k = 0; k < jj; k++) p = p + delta;
-    steps -= jj;
-    return 0;
+    j >>= 2;
   }
+  const int jj = j > 7 ? 7 : j;  // short skips: the reference's own adds, no fetches
   p = p + delta;
-  steps -= 1;
+  for (int k = 1; k < jj; k++) p = p + delta;
+  steps -= jj;
   return 0;
 }
 
@@ -366,10 +365,10 @@ struct Tracer {
   RM_DEV bool surely_no_walk(const BoxFilter& f, float t, float g) {
     if (!f.ok) return false;
     const float m = f.slack + 8e-6f * __builtin_fabsf(t);
-    return g <= 0.0f                     // entry distance is >= 0 or -1: never < g
-           || f.far0 - t < -m            // box entirely behind: b < 0 <= a
-           || f.far0 - f.near0 < -m      // the line misses the box: b < a
-           || f.near0 - t > g + m;       // entry farther than the ground term
+    return (g <= 0.0f)                   // entry distance is >= 0 or -1: never < g
+           | (f.far0 - t < -m)           // box entirely behind: b < 0 <= a
+           | (f.far0 - f.near0 < -m)     // the line misses the box: b < a
+           | (f.near0 - t > g + m);      // entry farther than the ground term
   }
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
     const RmOpts& o = *sc.o;
