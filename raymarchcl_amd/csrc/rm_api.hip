@@ -123,6 +123,8 @@ int check_opts(rm_ctx* c, const void* opts544, int n) {
 int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   *out = rmk::Accel{};
   if (!c->use_accel) return RM_OK;
+  // walk_step indexes with 24-bit multiplies: fall back to the plain march otherwise
+  if ((long long)c->ry * c->rz >= (1 << 24) || c->rx >= (1 << 24)) return RM_OK;
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
   if (c->accel_iso != iso) {
     HIP_TRY(c->dist_buf.reserve(vox));

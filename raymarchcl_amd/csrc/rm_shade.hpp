@@ -175,10 +175,13 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
   const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
   if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
-  const int cell = qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx;
+  // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
+  // derived structures when ry*rz < 2^24 and rx < 2^24) and an unsigned 32-bit offset
+  const unsigned cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
+                                 (unsigned)o.voxelRes[0]) + (unsigned)qx;
   const int d = dist8[cell];
   if (d == 0) {
-    *cell_out = cell;
+    *cell_out = (int)cell;
     return 1;
   }
   // (the floor argument above needs p >= 0; tiny p also means tiny binades)
