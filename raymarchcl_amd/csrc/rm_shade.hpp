@@ -376,33 +376,49 @@ struct Tracer {
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
-    r.distance = o.startDist;
+    float dist = o.startDist;
     BoxFilter flt;
     flt.ok = false;
     if (!COUNT) flt = make_filter(ro, rdir);
+    // Only the LAST estimate's position, code and normal survive the loop
+    // (renderer.cl:244-246 overwrite them every turn), so the filtered turns -- the
+    // large majority -- just remember that they were last; `last_t` is the distance
+    // the surviving position was computed at.
+    float last_t = dist, scode = 0.0f;
+    bool last_filtered = false, any = false;
     while (--maxSteps >= 0) {
-      r.pos = mads(rdir, r.distance, ro);
-      float sd, scode;
-      const float h = r.pos.y + o.groundY;  // renderer.cl:211
+      last_t = dist;
+      any = true;
+      float sd;
+      const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
       const float g = h < 1e5f ? h : 1e5f;
       RM_WS(ws_iters++);
-      if (!COUNT && surely_no_walk(flt, r.distance, g)) {
+      if (!COUNT && surely_no_walk(flt, dist, g)) {
         RM_WS(ws_filtered++);
         sd = g;
         scode = h < 1e5f ? h : -1.0f;
-        r.normal = (g < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;  // renderer.cl:212
+        last_filtered = true;
       } else {
-        scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd, scode, r.normal);
+        scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal);
+        last_filtered = false;
       }
+      if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) break;
+      dist += sd;
+    }
+    if (any) {
+      r.pos = mads(rdir, last_t, ro);
       r.objectID = rmd::f2i(scode);
-      if (__builtin_fabsf(sd) <= o.eps || r.distance >= maxDist) break;
-      r.distance += sd;
+      if (last_filtered) {  // renderer.cl:212 for the ground / sky term
+        const float g = (rdir.y * last_t + ro.y) + o.groundY;
+        r.normal = (g < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;
+      }
     }
-    if (r.distance >= maxDist) {
-      r.pos = mads(rdir, r.distance, ro);
+    if (dist >= maxDist) {
+      r.pos = mads(rdir, dist, ro);
       r.objectID = -1;
-      r.distance = 1000.0f;
+      dist = 1000.0f;
     }
+    r.distance = dist;
   }
 
   RM_DEV v3 sky(v3 dir) { return sky_of(*sc.o, dir); }
