@@ -56,36 +56,6 @@ struct Scene {
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
 };
 
-// Exact multi-step advance of the fixed-step march (used with dist8).
-//
-// The reference walks p <- fl(p + delta) once per sample.  While a component
-// stays inside one binade [2^e, 2^(e+1)) every add rounds to the same grid of
-// spacing u = 2^(e-23), so the rounded increment D = fl(p+delta) - p is a
-// CONSTANT multiple of u (the only exception, an exact tie, settles after one
-// add), and k further adds land exactly on p + k*D, which float arithmetic
-// evaluates without error (both k*D and the sum are multiples of u below
-// 2^24 u).  advance_exact() therefore takes two real adds, measures D on the
-// second, and jumps the remaining k-2 samples in one step -- provided start,
-// warm-up and landing points share their binade component-wise; otherwise it
-// reports failure and the caller falls back to single adds.
-// (straight-line on purpose: a short-circuit chain of six comparisons compiles to
-//  six nested exec-mask branches on this target)
-RM_DEV bool advance_exact(v3& p, v3 delta, int k) {
-  const v3 p1 = p + delta;
-  const v3 p2 = p1 + delta;
-  const v3 D = p2 - p1;
-  const float m = (float)(k - 2);
-  const v3 q = V(p2.x + m * D.x, p2.y + m * D.y, p2.z + m * D.z);
-  // sign + exponent of start, warm-up and landing point must agree per component
-  const uint32_t px = __float_as_uint(p.x), py = __float_as_uint(p.y), pz = __float_as_uint(p.z);
-  const uint32_t diff = (px ^ __float_as_uint(p2.x)) | (py ^ __float_as_uint(p2.y)) |
-                        (pz ^ __float_as_uint(p2.z)) | (px ^ __float_as_uint(q.x)) |
-                        (py ^ __float_as_uint(q.y)) | (pz ^ __float_as_uint(q.z));
-  const bool ok = (diff & 0xff800000u) == 0u;
-  p = V(ok ? q.x : p.x, ok ? q.y : p.y, ok ? q.z : p.z);
-  return ok;
-}
-
 // ---- leaf routines shared by the straight (Tracer) and wave-scheduled
 // (rm_wave.hpp) forms; `o` points at the option record in device memory ----
 
@@ -163,6 +133,8 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // 2: the walk ends without a hit (out of samples / left the grid / cannot reach
 // anything in the samples left).
 //
+// The samples that are skipped still advance p by the reference's sequential adds,
+// so the positions of all later samples -- and the hit position -- are bit-identical.
 // Skip length: dist8 = d at cell q means every cell within Chebyshev distance d-1
 // of q is empty and inside the grid.  Sample k lies <= k*s cells from sample 0
 // along the fastest axis (s = cells per sample), so its cell differs from q by at
@@ -188,17 +160,12 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   const bool roomy = fminf(fminf(p.x, p.y), p.z) >= 0.015625f;
   int j = roomy ? 1 + (int)((float)(d - 1) * inv_s) : 1;
   if (j >= steps) return 2;  // no sample left that could hit anything
-  if (j >= 8) {
-    if (advance_exact(p, delta, j)) {
-      steps -= j;
-      return 0;
-    }
-    j >>= 2;
-  }
-  const int jj = j > 7 ? 7 : j;  // short skips: the reference's own adds, no fetches
+  // skip = the reference's own adds (renderer.cl:233) without the fetches.  (A closed
+  // form p + j*D, exact while p stays inside one binade, was measured slower: three
+  // adds per skipped sample are cheaper than its bookkeeping and failure path.)
   p = p + delta;
-  for (int k = 1; k < jj; k++) p = p + delta;
-  steps -= jj;
+  for (int k = 1; k < j; k++) p = p + delta;
+  steps -= j;
   return 0;
 }
 
