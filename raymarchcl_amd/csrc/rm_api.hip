@@ -373,6 +373,7 @@ int rm_create(int device_id, rm_ctx** out) {
 void rm_destroy(rm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  rmk::dump_work_stats();
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf, &c->queue_buf, &c->work_buf,
                     &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};

@@ -11,6 +11,7 @@ struct Counters;
 inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / parts; }
 // number of 8x8 tiles covering work-items 0..n-1 of an image `resx` wide
 int tiles_total(int resx, int n);
+void dump_work_stats();  // no-op unless built with -DRM_WORK_STATS
 
 struct Accel {  // nullptrs = not available: the kernels then run the plain fixed-step march
   const uint8_t* dist = nullptr;

@@ -15,9 +15,18 @@
 // is what costs it 560 B of scratch per lane on this chip.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
 #include "rm_wave.hpp"
+
+#ifdef RM_WORK_STATS
+// debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
+// over all lanes: samples, outer marches, their turns, filtered turns, voxel walks,
+// dist8 fetches, samples advanced, AO loops.  rmk::dump_work_stats() prints and resets.
+__device__ unsigned long long g_work_stats[8];
+#endif
 
 namespace {
 
@@ -143,6 +152,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   if (pp > 1) tr.set_pass(mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts_all[pass].time);
   const rmk::v3 col = tr.shade(id);
   staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
+#ifdef RM_WORK_STATS
+  {
+    const unsigned int v[8] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
+                               tr.ws_steps, tr.ws_probes};
+    for (int k = 0; k < 8; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
+  }
+#endif
 }
 
 // The two halves of a sample (Tracer::trace_chain / shade_from_hits): same grid
@@ -422,6 +438,20 @@ __global__ void prims_kernel(int op, const float* __restrict__ a, const float* _
 namespace rmk {
 
 int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
+
+void dump_work_stats() {
+#ifdef RM_WORK_STATS
+  unsigned long long h[8] = {0};
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
+  const double n = h[0] ? (double)h[0] : 1.0;
+  fprintf(stderr, "[work stats] samples=%llu per sample: marches=%.2f turns=%.2f filtered=%.2f walks=%.2f "
+                  "fetches=%.2f steps_advanced=%.2f ao_loops=%.2f\n",
+          h[0], h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n);
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
+#endif
+}
 
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,

@@ -163,8 +163,22 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   // skip = the reference's own adds (renderer.cl:233) without the fetches.  (A closed
   // form p + j*D, exact while p stays inside one binade, was measured slower: three
   // adds per skipped sample are cheaper than its bookkeeping and failure path.)
+  // (on average 5 samples are advanced per fetch: the adds are unrolled by four so that
+  //  the loop bookkeeping does not cost more than the adds themselves)
   p = p + delta;
-  for (int k = 1; k < j; k++) p = p + delta;
+  int k = j - 1;
+  while (k >= 4) {
+    p = p + delta;
+    p = p + delta;
+    p = p + delta;
+    p = p + delta;
+    k -= 4;
+  }
+  if (k & 2) {
+    p = p + delta;
+    p = p + delta;
+  }
+  if (k & 1) p = p + delta;
   steps -= j;
   return 0;
 }
@@ -181,7 +195,8 @@ struct Tracer {
   Counters cnt;  // per-lane, only touched when COUNT
 #ifdef RM_WORK_STATS
   // debug build only: what the accelerated path actually executes
-  unsigned int ws_iters = 0, ws_filtered = 0, ws_walks = 0, ws_lookups = 0, ws_jumps = 0;
+  unsigned int ws_iters = 0, ws_filtered = 0, ws_walks = 0, ws_lookups = 0, ws_jumps = 0, ws_rays = 0,
+               ws_probes = 0, ws_steps = 0;
 #define RM_WS(x) (x)
 #else
 #define RM_WS(x) ((void)0)
@@ -262,7 +277,9 @@ struct Tracer {
         for (;;) {
           int cell = 0;
           RM_WS(ws_lookups++);
+          RM_WS(ws_steps += (unsigned)steps);
           const int r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
+          RM_WS(ws_steps -= (unsigned)steps);
           if (r == 0) continue;
           if (r == 1) {
             const uint32_t w = sc.surf[cell];
@@ -343,6 +360,7 @@ struct Tracer {
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
+    RM_WS(ws_rays++);
     float dist = o.startDist;
     BoxFilter flt;
     flt.ok = false;
@@ -431,6 +449,7 @@ struct Tracer {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.ao_calls++;
     float ao = 1.0f;
+    RM_WS(ws_probes++);
     float d = 0.0f;
     uint32_t seed =
         rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
