@@ -248,15 +248,17 @@ struct Tracer {
   }
 
   // distance estimate: renderer.cl:209-237
+  // known_inside: the caller has established (slab-test filter) that rpos lies inside
+  // the clip box by a margin; the reference's slab test then returns exactly +0.
   RM_DEV void scene_distance(v3 rpos, v3 dir, int steps, bool smooth, float& dist, float& code,
-                             v3& nrm) {
+                             v3& nrm, bool known_inside = false) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.dts_calls++;
     const float h = rpos.y + o.groundY;
     float rd, rc;
     if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
     nrm = (rd < 1e5f) ? V(0.f, 1.f, 0.f) : -dir;
-    const float t_in = box_entry(rpos, dir);
+    const float t_in = known_inside ? 0.0f : box_entry(rpos, dir);
     if (t_in >= 0.0f && t_in < rd) {
       const float sf = (float)steps * 0.5f;
       const v3 ivs = ld3(o.invVoxelScale);
@@ -357,6 +359,12 @@ struct Tracer {
            | (f.far0 - f.near0 < -m)     // the line misses the box: b < a
            | (f.near0 - t > g + m);      // entry farther than the ground term
   }
+  // true when the position at distance t is certainly inside the clip box and the ground
+  // term is positive by a margin: the reference's slab test returns exactly +0 < g
+  RM_DEV bool surely_inside(const BoxFilter& f, float t, float g) {
+    const float m = f.slack + 8e-6f * __builtin_fabsf(t);
+    return f.ok & (f.near0 - t < -m) & (f.far0 - t > m) & (g > m);
+  }
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
@@ -384,7 +392,8 @@ struct Tracer {
         scode = h < 1e5f ? h : -1.0f;
         last_filtered = true;
       } else {
-        scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal);
+        const bool inside = !COUNT && surely_inside(flt, dist, g);
+        scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
         last_filtered = false;
       }
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) break;
