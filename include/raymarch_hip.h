@@ -151,6 +151,38 @@ int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
  * pointer may be NULL. */
 int rm_debug_get_accel(rm_ctx* ctx, int iso, uint8_t* dist_out, uint32_t* surf_out);
 
+/* ---- host-side parameter layer (no device needed) ------------------------
+ * The reference builds its inputs in Clojure; a non-Python host gets the same
+ * helpers here.  NaN in a double field of rm_render_args means "not given"
+ * (Clojure's `(or x default)`).  Results are byte-identical to the Python layer. */
+typedef struct rm_render_args {
+  int width, height;   /* :width :height */
+  int vres[3];         /* :vres */
+  int iter;            /* :iter  (frameBlend = 1/iter) */
+  double t;            /* :t     (pass time; make-render-option-buffer uses i*0.333) */
+  double eyepos[3];    /* :eyepos      default [2 0 2] */
+  double targetpos[3]; /* :targetpos   default [0 -0.15 0] */
+  double fov_deg;      /* :fov         default 90 */
+  double dof;          /* :dof         default 0.001 */
+  double gamma;        /* :gamma       default 1.5 */
+  double ground_y;     /* :groundY     default 1.05 */
+  double voxel_size;   /* :voxelSize   default 1/vres[0] */
+  const char* mat;     /* :mat  "orange-stripes" | "metal" | "metal2" | "ao" (unknown/NULL -> "ao") */
+} rm_render_args;
+/* render-options (core.clj:28-74) + structgen encoding -> one 544-byte TRenderOpts */
+int rm_render_options(const rm_render_args* args, void* out544);
+/* compute-eyepos (core.clj:150-152) */
+int rm_compute_eyepos(double theta_deg, double dist, double y, double out_xyz[3]);
+/* generate-scatter-offsets (generators.clj:8-16) with a seed instead of nanoTime:
+ * out = 0x4000 unit 4-vectors (RM_TABLE_FLOATS floats) */
+int rm_make_scatter_table(uint64_t seed, float* out);
+/* make-gyroid-volume (generators.clj:27-42) on the host */
+int rm_make_gyroid_host(int rx, int ry, int rz, uint8_t* out);
+/* save-volume / load-volume (io.clj:9-33) */
+int rm_vox_save(const char* path, int rx, int ry, int rz, const uint8_t* voxels);
+int rm_vox_info(const char* path, int* rx, int* ry, int* rz);
+int rm_vox_load(const char* path, uint8_t* out, size_t capacity);
+
 /* Device-vs-host checks of the float primitives the parity contract rests on.
  * op: 0 a/b, 1 sqrt(a), 2 exp(a), 3 exp2(a), 4 pow(a,b), 5 (int)a [x86],
  *     6 (uint)a [x86], 7 convert_int_sat(a), 8 a*b+c unfused (c = a).

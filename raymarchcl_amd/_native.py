@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libraymarch_hip.so")
-SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_stream.hip", "rm_api.hip"]
+SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_stream.hip", "rm_api.hip", "rm_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 OPTS_BYTES = 544
@@ -27,6 +27,8 @@ EXPORTS = [
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_selftest_prims",
+    "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
+    "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
 
 
@@ -34,6 +36,15 @@ class RmError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libraymarch_hip: {msg} (code {code})")
         self.code = code
+
+
+class RenderArgs(ctypes.Structure):
+    """rm_render_args of include/raymarch_hip.h; NaN = not given."""
+    _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("vres", ctypes.c_int * 3),
+                ("iter", ctypes.c_int), ("t", ctypes.c_double), ("eyepos", ctypes.c_double * 3),
+                ("targetpos", ctypes.c_double * 3), ("fov_deg", ctypes.c_double), ("dof", ctypes.c_double),
+                ("gamma", ctypes.c_double), ("ground_y", ctypes.c_double), ("voxel_size", ctypes.c_double),
+                ("mat", ctypes.c_char_p)]
 
 
 class Counters(ctypes.Structure):

@@ -303,6 +303,9 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
 
 extern "C" {
 
+// used by rm_host.cpp (host-only translation unit) to report through rm_last_error()
+int rm_host_fail_(int code, const char* msg) { return fail(code, "%s", msg); }
+
 const char* rm_last_error(void) { return g_err; }
 int rm_abi_version(void) { return 1; }
 

@@ -1,0 +1,84 @@
+"""The host-side parameter layer of the C ABI (csrc/rm_host.cpp) produces the same
+bytes as the Python host layer (which tests/test_host_layer.py pins against the
+reference's values).  No GPU needed."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+import raymarchcl_amd as rm
+from raymarchcl_amd import generators as gen
+from raymarchcl_amd import structs, vio
+
+NAN = float("nan")
+
+
+def _args(native, **kw):
+    a = native.RenderArgs()
+    a.width, a.height = kw.get("width", 640), kw.get("height", 360)
+    v = kw.get("vres", [256, 256, 256])
+    a.vres[0], a.vres[1], a.vres[2] = v
+    a.iter, a.t = kw.get("iter", 4), kw.get("t", 0.0)
+    for name in ("eyepos", "targetpos"):
+        val = kw.get(name)
+        for i in range(3):
+            getattr(a, name)[i] = NAN if val is None else val[i]
+    a.fov_deg = kw.get("fov", NAN) if kw.get("fov") is not None else NAN
+    a.dof = kw.get("dof", NAN) if kw.get("dof") is not None else NAN
+    a.gamma = kw.get("gamma", NAN) if kw.get("gamma") is not None else NAN
+    a.ground_y = kw.get("groundY", NAN) if kw.get("groundY") is not None else NAN
+    a.voxel_size = kw.get("voxelSize", NAN) if kw.get("voxelSize") is not None else NAN
+    a.mat = kw["mat"].encode() if kw.get("mat") is not None else None
+    return a
+
+
+@pytest.mark.parametrize("kw", [
+    dict(mat="orange-stripes", eyepos=rm.compute_eyepos(-45, 2.25, 0.35), targetpos=[0, -0.4, 0], dof=0.025, t=0.333),
+    dict(mat="metal", iter=16, t=15 * 0.333), dict(mat="metal2", fov=115, width=1280, height=720),
+    dict(mat="ao", vres=[64, 40, 48], voxelSize=0.01, groundY=0.9, gamma=2.2),
+    dict(mat="no-such-preset"), dict(mat=None, dof=0.0),
+])
+def test_render_options_bytes_equal_python(native, kw):
+    L = native.lib()
+    out = ctypes.create_string_buffer(544)
+    a = _args(native, **kw)
+    assert L.rm_render_options(ctypes.byref(a), out) == 0
+    py = dict(width=640, height=360, vres=[256, 256, 256], iter=4, t=0.0)
+    py.update(kw)
+    assert out.raw == structs.encode_bytes(rm.render_options(**py))
+
+
+def test_eyepos_scatter_gyroid_vox(native, tmp_path):
+    L = native.lib()
+    L.rm_compute_eyepos.argtypes = [ctypes.c_double] * 3 + [ctypes.POINTER(ctypes.c_double * 3)]
+    e = (ctypes.c_double * 3)()
+    assert L.rm_compute_eyepos(-45.0, 2.25, 0.35, ctypes.byref(e)) == 0
+    assert list(e) == rm.compute_eyepos(-45, 2.25, 0.35)
+    # scatter table: bit-identical to the numpy generator
+    L.rm_make_scatter_table.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+    t = np.zeros(0x4000 * 4, np.float32)
+    assert L.rm_make_scatter_table(1003, t.ctypes.data) == 0
+    assert np.array_equal(t.view(np.uint32), gen.generate_scatter_offsets(0x4000, seed=1003).view(np.uint32))
+    # gyroid volume (same libm cos/sin as numpy)
+    L.rm_make_gyroid_host.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    v = np.zeros(64 * 48 * 80, np.uint8)
+    assert L.rm_make_gyroid_host(64, 48, 80, v.ctypes.data) == 0
+    assert (v != gen.make_gyroid_volume((64, 48, 80))).mean() < 1e-6
+    # .vox files are interchangeable with the Python reader / writer
+    L.rm_vox_save.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    L.rm_vox_info.argtypes = [ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+    L.rm_vox_load.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    p = str(tmp_path / "a.vox").encode()
+    assert L.rm_vox_save(p, 64, 48, 80, v.ctypes.data) == 0
+    back, res = vio.load_volume(p.decode())
+    assert res == (64, 48, 80) and np.array_equal(back, v)
+    q = str(tmp_path / "b.vox")
+    vio.save_volume(q, (64, 48, 80), v)
+    rx, ry, rz = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert L.rm_vox_info(q.encode(), ctypes.byref(rx), ctypes.byref(ry), ctypes.byref(rz)) == 0
+    assert (rx.value, ry.value, rz.value) == (64, 48, 80)
+    w = np.zeros(v.size, np.uint8)
+    assert L.rm_vox_load(q.encode(), w.ctypes.data, w.size) == 0 and np.array_equal(w, v)
+    assert L.rm_vox_load(q.encode(), w.ctypes.data, 10) != 0 and b"too small" in L.rm_last_error()
+    assert L.rm_vox_info(b"/nonexistent.vox", ctypes.byref(rx), ctypes.byref(ry), ctypes.byref(rz)) != 0
