@@ -379,25 +379,40 @@ struct Tracer {
     // the surviving position was computed at.
     float last_t = dist, scode = 0.0f;
     bool last_filtered = false, any = false;
-    while (--maxSteps >= 0) {
-      last_t = dist;
-      any = true;
-      float sd;
-      const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
-      const float g = h < 1e5f ? h : 1e5f;
-      RM_WS(ws_iters++);
-      if (!COUNT && surely_no_walk(flt, dist, g)) {
+    // Two nested loops instead of the reference's one: the inner loop runs a lane
+    // through consecutive turns whose estimate is certainly the ground / sky term
+    // (cheap, ~85 % of all turns) WITHOUT waiting for the other lanes; the outer
+    // loop then lets every lane that reached a turn needing the real estimate (slab
+    // test + voxel walk) take it together.  With a single loop the wavefront paid a
+    // full walk in almost every turn because some lane always needed one; now it
+    // pays one per round, and a ray has only 2-3 such turns.  Per lane the sequence
+    // of operations is unchanged.
+    bool finished = false;
+    while (!finished) {
+      bool need_estimate = false;
+      float g = 0.0f;
+      while (true) {
+        if (--maxSteps < 0) { finished = true; break; }
+        last_t = dist;
+        any = true;
+        const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
+        g = h < 1e5f ? h : 1e5f;
+        RM_WS(ws_iters++);
+        if (COUNT || !surely_no_walk(flt, dist, g)) { need_estimate = true; break; }
         RM_WS(ws_filtered++);
-        sd = g;
         scode = h < 1e5f ? h : -1.0f;
         last_filtered = true;
-      } else {
+        if (__builtin_fabsf(g) <= o.eps || dist >= maxDist) { finished = true; break; }
+        dist += g;
+      }
+      if (need_estimate) {
+        float sd;
         const bool inside = !COUNT && surely_inside(flt, dist, g);
         scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
         last_filtered = false;
+        if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) finished = true;
+        else dist += sd;
       }
-      if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) break;
-      dist += sd;
     }
     if (any) {
       r.pos = mads(rdir, last_t, ro);
