@@ -25,13 +25,13 @@
 // debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
 // over all lanes: samples, outer marches, their turns, filtered turns, voxel walks,
 // dist8 fetches, samples advanced, AO loops.  rmk::dump_work_stats() prints and resets.
-__device__ unsigned long long g_work_stats[8];
+__device__ unsigned long long g_work_stats[16];
 #endif
 
 namespace {
 
 constexpr int kTile = 8;            // tile edge in pixels; 64 px == one wavefront
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 1;  // one wavefront per workgroup: finest dispatch granularity (measured best)
 
 struct TileGeom {
   int tiles_x, tiles_total;
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
 #ifdef RM_WORK_STATS
   {
-    const unsigned int v[8] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
-                               tr.ws_steps, tr.ws_probes};
-    for (int k = 0; k < 8; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
+    const unsigned int v[11] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
+                                tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
+    for (int k = 0; k < 11; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
   }
 #endif
 }
@@ -441,14 +441,18 @@ int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
 void dump_work_stats() {
 #ifdef RM_WORK_STATS
-  unsigned long long h[8] = {0};
+  unsigned long long h[16] = {0};
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
   const double n = h[0] ? (double)h[0] : 1.0;
   fprintf(stderr, "[work stats] samples=%llu per sample: marches=%.2f turns=%.2f filtered=%.2f walks=%.2f "
                   "fetches=%.2f steps_advanced=%.2f ao_loops=%.2f\n",
           h[0], h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n);
-  unsigned long long z[8] = {0};
+  fprintf(stderr, "[work stats] lane utilisation of the loops: walk %.1f%% (fetches / lane-slots), "
+                  "filtered turns %.1f%%, estimate turns %.1f%%\n",
+          100.0 * h[5] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[9] ? h[9] : 1),
+          100.0 * (h[2] - h[3]) / (h[10] ? h[10] : 1));
+  unsigned long long z[16] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
 #endif
 }

@@ -197,6 +197,12 @@ struct Tracer {
   // debug build only: what the accelerated path actually executes
   unsigned int ws_iters = 0, ws_filtered = 0, ws_walks = 0, ws_lookups = 0, ws_jumps = 0, ws_rays = 0,
                ws_probes = 0, ws_steps = 0;
+  // lane-slots a wavefront spends in a loop (64 per trip, charged to its first active lane)
+  unsigned int wv_walk = 0, wv_filt = 0, wv_est = 0;
+  RM_DEV unsigned int wave_slots() {
+    const unsigned long long act = __ballot(1);
+    return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? 64u : 0u;
+  }
 #define RM_WS(x) (x)
 #else
 #define RM_WS(x) ((void)0)
@@ -279,6 +285,7 @@ struct Tracer {
         for (;;) {
           int cell = 0;
           RM_WS(ws_lookups++);
+          RM_WS(wv_walk += wave_slots());
           RM_WS(ws_steps += (unsigned)steps);
           const int r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
           RM_WS(ws_steps -= (unsigned)steps);
@@ -398,6 +405,7 @@ struct Tracer {
         const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
         g = h < 1e5f ? h : 1e5f;
         RM_WS(ws_iters++);
+        RM_WS(wv_filt += wave_slots());
         if (COUNT || !surely_no_walk(flt, dist, g)) { need_estimate = true; break; }
         RM_WS(ws_filtered++);
         scode = h < 1e5f ? h : -1.0f;
@@ -407,6 +415,7 @@ struct Tracer {
       }
       if (need_estimate) {
         float sd;
+        RM_WS(wv_est += wave_slots());
         const bool inside = !COUNT && surely_inside(flt, dist, g);
         scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
         last_filtered = false;
