@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="successive frames alternate between this many HIP streams (1 = strictly serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
@@ -119,7 +121,7 @@ def main():
     vox, vres, opts, mc = build_inputs(wl)
     n, width, spp = wl["w"] * wl["h"], wl["w"], wl["spp"]
     fr = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev,
-                                want_pixels=True, want_argb=True)
+                                want_pixels=True, want_argb=True, frames_in_flight=args.frames_in_flight)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -148,8 +150,11 @@ def main():
     # frame on the stream they run on (torch's current stream, handed to the library);
     # measured on extra frames right after the timed region so the event reads do not
     # perturb it.
+    # (one frame at a time here: overlapped frames would stretch each other's launch)
     launches = 1
     for _ in range(5):
+        torch.cuda.synchronize(dev)
+        fr.frame = 0
         fr.render()
         ms, launches = fr.ctx.last_frame_timing()
         kernel_ms.append(ms / launches)
@@ -190,7 +195,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]],
-                       "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+                       "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "frames_in_flight": len(fr.slots)},
             "all_rays_per_s_M": round((c["rays"] + c["ao_calls"]) * args.steps / elapsed / 1e6, 2),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -12,7 +12,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libraymarch_hip.so")
+# RAYMARCH_LIB: load (and build) another file of this directory instead, e.g. an A/B
+# variant built with extra flags by tools/ab_build.py; the product default is the name below
+LIB_PATH = os.path.join(HERE, os.path.basename(os.environ.get("RAYMARCH_LIB", "libraymarch_hip.so")))
 SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_stream.hip", "rm_api.hip", "rm_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

@@ -622,7 +622,7 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
 int rm_selftest_prims(rm_ctx* c, int op, const float* a, const float* b, uint32_t* out, int n) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!a || !out || n < 0 || op < 0 || op > 8) return fail(RM_EINVAL, "bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 9) return fail(RM_EINVAL, "bad argument");
   if (n == 0) return RM_OK;
   const size_t bytes = (size_t)n * 4;
   HIP_TRY(c->prim_a.reserve(bytes));

@@ -58,6 +58,35 @@ RM_DEV int32_t convert_int_sat(float x) {
   return r;
 }
 
+// x / b, correctly rounded, for several x sharing one divisor: with y = RN(1/b),
+//   q = RN(x*y);  r = x - b*q (exact in one fma);  RN(q + r*y) = RN(x/b)
+// (Markstein's theorem: holds when the significand of b is not all ones and nothing
+// over/underflows -- the range guards; anything else takes the IEEE division.  Checked
+// exhaustively over every float x for b = 48, 96 and on 2.6e8 random (x, b) pairs,
+// tests/test_det_math.py holds the same check against the built library.)  Three
+// instructions per quotient instead of the twelve of a division sequence.
+struct Divisor {
+  float b, y;
+  bool ok;
+};
+RM_DEV Divisor make_divisor(float b) {
+  Divisor d;
+  d.b = b;
+  d.y = 1.0f / b;
+  const float ab = __builtin_fabsf(b);
+  d.ok = (ab >= 0x1p-30f) & (ab <= 0x1p30f) & ((__float_as_uint(b) & 0x7fffffu) != 0x7fffffu);
+  return d;
+}
+RM_DEV float div_by(float x, const Divisor& d) {
+  const float ax = __builtin_fabsf(x);
+  if (d.ok & (ax >= 0x1p-90f) & (ax <= 0x1p90f)) {
+    const float q = x * d.y;
+    const float r = __builtin_fmaf(-d.b, q, x);
+    return __builtin_fmaf(r, d.y, q);
+  }
+  return x / d.b;
+}
+
 RM_DEV double bits2d(uint64_t u) { return __longlong_as_double((long long)u); }
 RM_DEV uint64_t d2bits(double d) { return (uint64_t)__double_as_longlong(d); }
 

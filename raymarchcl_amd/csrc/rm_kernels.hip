@@ -428,6 +428,7 @@ __global__ void prims_kernel(int op, const float* __restrict__ a, const float* _
     case 6: r = rmd::f2u(x); break;
     case 7: r = (uint32_t)rmd::convert_int_sat(x); break;
     case 8: r = __float_as_uint(x * y + x); break;
+    case 9: r = __float_as_uint(rmd::div_by(x, rmd::make_divisor(y))); break;
     default: break;
   }
   out[i] = r;

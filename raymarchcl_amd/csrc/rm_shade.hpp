@@ -183,6 +183,16 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   return 0;
 }
 
+// Two exact instruction-count reductions that measured SLOWER on the 64-VGPR build
+// (10.95 ms without, 10.98 / 11.10 / 11.16 ms with the first / second / both): the kernel
+// is bound by exposed fetch latency and register pressure, not by VALU issue.  Kept
+// switchable for re-measuring after changes to the register budget (tools/ab_build.py).
+#ifndef RM_FASTDIV
+#define RM_FASTDIV 0      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
+#endif
+#ifndef RM_INSIDE_TEST
+#define RM_INSIDE_TEST 0  // AO probes: skip the slab test when the position is inside the box
+#endif
 template <bool COUNT, bool ACCEL = false>
 struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
@@ -264,11 +274,27 @@ struct Tracer {
     float rd, rc;
     if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
     nrm = (rd < 1e5f) ? V(0.f, 1.f, 0.f) : -dir;
+    // A position inside the clip box by a margin makes every slab pair (neg, pos)/d:
+    // all three entry parameters are negative (or -inf), all exits positive, and the
+    // reference's slab test returns max(.., 0) = exactly +0 -- without six divisions.
+    // (AO probes start on a surface inside the box and almost always qualify.)
+    if (ACCEL && RM_INSIDE_TEST && !known_inside) {
+      const float m = 1e-4f;
+      known_inside = (rpos.x - o.voxelBoundsMin[0] > m) & (o.voxelBoundsMax[0] - rpos.x > m) &
+                     (rpos.y - o.voxelBoundsMin[1] > m) & (o.voxelBoundsMax[1] - rpos.y > m) &
+                     (rpos.z - o.voxelBoundsMin[2] > m) & (o.voxelBoundsMax[2] - rpos.z > m);
+    }
     const float t_in = known_inside ? 0.0f : box_entry(rpos, dir);
     if (t_in >= 0.0f && t_in < rd) {
       const float sf = (float)steps * 0.5f;
       const v3 ivs = ld3(o.invVoxelScale);
-      const v3 delta = V(dir.x / sf, dir.y / sf, dir.z / sf) * ivs;
+      v3 delta;
+      if (ACCEL && RM_FASTDIV) {
+        const rmd::Divisor by_sf = rmd::make_divisor(sf);
+        delta = V(rmd::div_by(dir.x, by_sf), rmd::div_by(dir.y, by_sf), rmd::div_by(dir.z, by_sf)) * ivs;
+      } else {
+        delta = V(dir.x / sf, dir.y / sf, dir.z / sf) * ivs;
+      }
       v3 p = rpos + ld3(o.voxelBounds);
       if (t_in > 0.0f) p = mads(dir, t_in, p);
       p = p * ivs;
@@ -282,22 +308,23 @@ struct Tracer {
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
         RM_WS(ws_walks++);
         (void)s;
-        for (;;) {
-          int cell = 0;
+        // the loop holds nothing but the walk: a lane that finds its hit waits for the
+        // others and all hits are then evaluated together (inside the loop the compiler
+        // runs the hit code once per trip in which any lane finishes)
+        int cell = 0, r;
+        do {
           RM_WS(ws_lookups++);
           RM_WS(wv_walk += wave_slots());
           RM_WS(ws_steps += (unsigned)steps);
-          const int r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
+          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
           RM_WS(ws_steps -= (unsigned)steps);
-          if (r == 0) continue;
-          if (r == 1) {
-            const uint32_t w = sc.surf[cell];
-            nrm = surf_normal(w, smooth);
-            const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
-            const float d = length(rpos - hit) - o.voxelSize;
-            if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }
-          }
-          break;
+        } while (r == 0);
+        if (r == 1) {
+          const uint32_t w = sc.surf[cell];
+          nrm = surf_normal(w, smooth);
+          const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
+          const float d = length(rpos - hit) - o.voxelSize;
+          if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }
         }
       } else
       while (--steps >= 0) {

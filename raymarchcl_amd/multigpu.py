@@ -86,13 +86,34 @@ def gather_tiles(local_tiles, rank, world, dst=0, group=None):
     return None
 
 
+class _Slot:
+    """What one frame in flight owns: a HIP stream, a library context bound to it (its
+    staging buffers and derived structures), the tile accumulators and the outputs."""
+
+    def __init__(self, torch, _native, dev, stream, tpp, n, root, want_pixels, want_argb):
+        self.stream = stream
+        self.d_tiles = torch.zeros(tpp * TILE_PIXELS * 4, dtype=torch.float32, device=dev)
+        self.d_pixels = torch.empty(4 * n, dtype=torch.float32, device=dev) if (root and want_pixels) else None
+        self.d_argb = torch.empty(n, dtype=torch.int32, device=dev) if (root and want_argb) else None
+        self.ctx = _native.Context(dev.index or 0)
+        self.ctx.set_stream(stream.cuda_stream)
+
+
 class FrameRenderer:
     """Device-resident pipeline of one rank: inputs live in HBM as torch
-    tensors, kernels run on torch's current stream, and ``render()`` does
-    rm_frame_device -> (gather) -> rm_resolve_device on the root."""
+    tensors, kernels run on torch streams, and ``render()`` does
+    rm_frame_device -> (gather) -> rm_resolve_device on the root.
+
+    ``frames_in_flight`` > 1 renders successive frames (the reference's animation
+    loop, core.clj:202-208) on alternating HIP streams, each with its own staging and
+    output buffers: the last wavefronts of frame i (a sample takes ~0.4 ms from camera
+    ray to colour, so every launch ends with a tail of that length during which most
+    of the chip idles) overlap the first of frame i+1.  A frame's own kernels stay
+    ordered on its stream; per-frame results are unchanged.
+    """
 
     def __init__(self, vox, vres, opts_bytes, mc, n, width, rank=0, world=1, device=None,
-                 want_pixels=True, want_argb=True, group=None):
+                 want_pixels=True, want_argb=True, group=None, frames_in_flight=1):
         import torch
 
         from . import _native
@@ -109,28 +130,42 @@ class FrameRenderer:
         assert self.d_mc.numel() == self.iters * _native.TABLE_FLOATS
         self.tpp = _native.tiles_per_part(self.width, self.n, world)
         assert self.tpp == tiles_per_part(self.width, self.n, world)
-        self.d_tiles = torch.zeros(self.tpp * TILE_PIXELS * 4, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)  # inputs are uploaded before any slot's stream reads them
         root = rank == 0
-        self.d_pixels = torch.empty(4 * self.n, dtype=torch.float32, device=dev) if (root and want_pixels) else None
-        self.d_argb = torch.empty(self.n, dtype=torch.int32, device=dev) if (root and want_argb) else None
-        self.ctx = _native.Context(dev.index or 0)
-        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        self.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
-        self.ctx.check_device_opts(self.d_opts.data_ptr(), self.iters, self.n, self.width)
+        self.slots = []
+        for i in range(max(1, int(frames_in_flight))):
+            # slot 0 keeps torch's current stream (what a caller with its own stream expects)
+            stream = torch.cuda.current_stream(dev) if i == 0 else torch.cuda.Stream(dev)
+            slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb)
+            slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
+            slot.ctx.check_device_opts(self.d_opts.data_ptr(), self.iters, self.n, self.width)
+            self.slots.append(slot)
+        self.frame = 0
+        # first slot under the names single-frame callers use
+        self.ctx, self.d_tiles = self.slots[0].ctx, self.slots[0].d_tiles
+        self.d_pixels, self.d_argb = self.slots[0].d_pixels, self.slots[0].d_argb
         torch.cuda.synchronize(dev)
 
     def render(self):
-        """One frame.  Asynchronous; results are valid on the root after a
-        stream synchronise."""
-        self.ctx.frame_device(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
-                              self.width, self.d_tiles.data_ptr(), self.rank, self.world)
-        allt = gather_tiles(self.d_tiles, self.rank, self.world, group=self.group)
-        if self.rank == 0:
-            self.ctx.resolve_device(allt.data_ptr(), self.world, self.d_opts.data_ptr(), self.n,
-                                    self.width,
-                                    self.d_pixels.data_ptr() if self.d_pixels is not None else None,
-                                    self.d_argb.data_ptr() if self.d_argb is not None else None)
-        return self.d_pixels, self.d_argb
+        """One frame.  Asynchronous; returns the (pixels, argb) tensors of the slot it
+        used, valid on the root once that slot's stream (or the device) is synchronised."""
+        torch = self.torch
+        slot = self.slots[self.frame % len(self.slots)]
+        self.frame += 1
+        with torch.cuda.stream(slot.stream):
+            slot.ctx.frame_device(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
+                                  self.width, slot.d_tiles.data_ptr(), self.rank, self.world)
+            allt = gather_tiles(slot.d_tiles, self.rank, self.world, group=self.group)
+            if self.rank == 0:
+                slot.ctx.resolve_device(allt.data_ptr(), self.world, self.d_opts.data_ptr(), self.n,
+                                        self.width,
+                                        slot.d_pixels.data_ptr() if slot.d_pixels is not None else None,
+                                        slot.d_argb.data_ptr() if slot.d_argb is not None else None)
+                if allt is not slot.d_tiles:
+                    allt.record_stream(slot.stream)
+        return slot.d_pixels, slot.d_argb
 
     def close(self):
-        self.ctx.close()
+        self.torch.cuda.synchronize(self.device)
+        for slot in self.slots:
+            slot.ctx.close()

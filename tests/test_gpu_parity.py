@@ -148,6 +148,28 @@ def test_config2_sampled_against_oracle_and_partition_invariance(gpu_ctx, oracle
     assert _eq(d_all.cpu().numpy().reshape(-1, 4)[idx].reshape(-1), px)
 
 
+def test_frames_in_flight(gpu_ctx, config2):
+    """Successive frames on alternating streams: every slot's frame == the serial frame,
+    also after a slot has been reused."""
+    import torch
+
+    from raymarchcl_amd import multigpu
+
+    sc = config2
+    gpu_ctx.set_volume(sc["vox"], sc["vres"])
+    px, argb = gpu_ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+    fr = multigpu.FrameRenderer(sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"], sc["w"],
+                                frames_in_flight=3)
+    assert len(fr.slots) == 3 and len({s.stream.cuda_stream for s in fr.slots}) == 3
+    outs = [fr.render() for _ in range(7)]
+    torch.cuda.synchronize()
+    assert len({o[0].data_ptr() for o in outs}) == 3
+    for d_px, d_argb in outs[-3:]:
+        assert _eq(d_px.cpu().numpy(), px)
+        assert np.array_equal(d_argb.cpu().numpy().view(np.uint32), argb)
+    fr.close()
+
+
 def test_frame_renderer_single_gpu(gpu_ctx, config2):
     """The torch-resident pipeline object bench.py uses == the host-buffer API."""
     import torch

@@ -44,6 +44,22 @@ def test_div_sqrt_mad_correctly_rounded(gpu_ctx):
         _same(gpu_ctx.selftest_prims(8, a, b), (a * b).astype(np.float32) + a)  # NOT fused
 
 
+def test_shared_divisor_division_is_ieee_division(gpu_ctx):
+    """rmd::div_by (one reciprocal + 3 instructions per quotient, rm_detmath.hpp) == x / b:
+    the general mix incl. specials (those take its IEEE fallback), and dense sweeps for
+    the divisors the voxel walk uses (maxVoxelIter/2, maxVoxelIter/4)."""
+    a, b = _inputs(5)
+    with np.errstate(all="ignore"):
+        _same(gpu_ctx.selftest_prims(9, a, b), a / b)
+        rng = np.random.default_rng(6)
+        for div in (96.0, 48.0, 24.0, 37.5, 3.0, 16777215.0 / 2.0, 1.9999999, 1e-31, 1e31):
+            # every exponent, random significands, both signs + a dense run of consecutive floats
+            x = (rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)).view(np.float32)
+            x = np.concatenate([x, (np.uint32(0x3f000000) + np.arange(1 << 18, dtype=np.uint32)).view(np.float32)])
+            d = np.full(x.size, div, np.float32)
+            _same(gpu_ctx.selftest_prims(9, x, d), x / d)
+
+
 def test_exp_exp2_pow_match_oracle_bitwise(gpu_ctx, oracle_mod):
     L = oracle_mod.restate_lib()
     rng = np.random.default_rng(2)
