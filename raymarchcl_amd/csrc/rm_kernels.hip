@@ -154,9 +154,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
 #ifdef RM_WORK_STATS
   {
-    const unsigned int v[11] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
-                                tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
-    for (int k = 0; k < 11; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
+    const unsigned int v[13] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
+                                tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est,
+                                tr.wv_walk_ao, tr.ws_lookups_ao};
+    for (int k = 0; k < 13; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
   }
 #endif
 }
@@ -453,6 +454,10 @@ void dump_work_stats() {
                   "filtered turns %.1f%%, estimate turns %.1f%%\n",
           100.0 * h[5] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[9] ? h[9] : 1),
           100.0 * (h[2] - h[3]) / (h[10] ? h[10] : 1));
+  fprintf(stderr, "[work stats] walk loop split: AO probes %.2f fetches/sample in %.1f%% of the lane-slots at "
+                  "%.1f%% utilisation; marches %.2f fetches/sample at %.1f%%\n",
+          h[12] / n, 100.0 * h[11] / (h[8] ? h[8] : 1), 100.0 * h[12] / (h[11] ? h[11] : 1),
+          (h[5] - h[12]) / n, 100.0 * (h[5] - h[12]) / (h[8] - h[11] ? h[8] - h[11] : 1));
   unsigned long long z[16] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
 #endif
@@ -498,11 +503,13 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
   while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;  // pass groups must tile `iter`
   const long long waves = my_tiles << pp_log2;
   long long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-  // blocks per tile row, for the XCD-aware order (whole image on this device only)
+  // blocks per tile row, for the XCD-aware order.  A partition (first, stride) whose
+  // stride divides the row length owns tiles_x/stride tiles of every row -- columns of
+  // tiles -- so its local slots still form rows and the same order applies.
   int bpr = 0;
-  if (xcd_rows && tile_stride == 1 && tile_first == 0 &&
-      ((long long)g.tiles_x << pp_log2) % kWavesPerBlock == 0) {
-    bpr = (int)(((long long)g.tiles_x << pp_log2) / kWavesPerBlock);
+  if (xcd_rows && g.tiles_x % tile_stride == 0 && tile_first < tile_stride &&
+      ((long long)(g.tiles_x / tile_stride) << pp_log2) % kWavesPerBlock == 0) {
+    bpr = (int)(((long long)(g.tiles_x / tile_stride) << pp_log2) / kWavesPerBlock);
     const long long rows = (blocks + bpr - 1) / bpr;
     blocks = ((rows + 7) / 8) * 8 * bpr;  // pad to groups of 8 rows; surplus blocks exit at once
   }

@@ -209,6 +209,8 @@ struct Tracer {
                ws_probes = 0, ws_steps = 0;
   // lane-slots a wavefront spends in a loop (64 per trip, charged to its first active lane)
   unsigned int wv_walk = 0, wv_filt = 0, wv_est = 0;
+  unsigned int wv_walk_ao = 0, ws_lookups_ao = 0;  // the share of the AO probes in wv_walk / ws_lookups
+  bool ws_in_ao = false;
   RM_DEV unsigned int wave_slots() {
     const unsigned long long act = __ballot(1);
     return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? 64u : 0u;
@@ -315,6 +317,8 @@ struct Tracer {
         do {
           RM_WS(ws_lookups++);
           RM_WS(wv_walk += wave_slots());
+          RM_WS(wv_walk_ao += ws_in_ao ? wave_slots() : 0u);
+          RM_WS(ws_lookups_ao += ws_in_ao ? 1u : 0u);
           RM_WS(ws_steps += (unsigned)steps);
           r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
           RM_WS(ws_steps -= (unsigned)steps);
@@ -520,7 +524,9 @@ struct Tracer {
       const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, normal));
       float sd, scode;
       v3 nn;
+      RM_WS(ws_in_ao = true);
       scene_distance(mads(n, d, pos), n, o.maxVoxelIter / 2, false, sd, scode, nn);
+      RM_WS(ws_in_ao = false);
       ao *= 1.0f - rmd::fmax_cl((d - sd) * o.aoAmp / d, 0.0f);
     }
     return ao;
