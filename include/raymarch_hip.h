@@ -85,6 +85,24 @@ int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int 
  * NULL, copies the rx*ry*rz bytes back.  The reference generates this grid on the
  * host in minutes for 512^3; here it takes milliseconds. */
 int rm_make_gyroid_volume(rm_ctx* ctx, int rx, int ry, int rz, uint8_t* voxels_out);
+/* gen/make-terrain (generators.clj:44-60) on the device, same conventions: two
+ * 4-voxel walls of byte 64 below y = int(ry*0.666) and sine-modulated columns of byte
+ * 255 on a 32-voxel grid.  Needs rx, rz >= 4 (and, like the reference, rz >= rx for
+ * the second wall to be complete). */
+int rm_make_terrain_volume(rm_ctx* ctx, int rx, int ry, int rz, uint8_t* voxels_out);
+/* Mesh vertex splatting (meshvoxel.clj): the vertices (n_vertices x 3 binary64, xyz
+ * interleaved) are scaled into a res^3 grid by mesh-scale (:16-25: bounding box,
+ * largest extent -> res, smaller extents centred) and every vertex sets byte 255 in
+ *   ks <  0: its own cell, if inside the grid            (voxelize,    :61-71)
+ *   ks >= 0: the clipped cube of cells within +-ks of it (voxelize-ks, :47-59)
+ * The result becomes the resident volume; voxels_out (res^3 bytes) may be NULL. */
+int rm_voxelize_vertices(rm_ctx* ctx, const double* xyz, long long n_vertices, int res, int ks,
+                         uint8_t* voxels_out);
+/* make-heatmap (meshvoxel.clj:73-87): a res x res ARGB image (row-major, as piksel's
+ * get-pixels returns it) -> in slab y a column of ceil(h) voxels of byte 255 over
+ * pixel (x, y), h = c > 0 ? (c > 224 ? 2 : max(2, c*amp)) : 0 with c = argb & 255.
+ * Columns are cut at res voxels (the reference would run into the next slab). */
+int rm_make_heatmap_volume(rm_ctx* ctx, const uint32_t* argb, int res, double amp, uint8_t* voxels_out);
 
 /* One NDRange of the RenderImage kernel (renderer.cl:478-494; pipeline step
  * core.clj:84-89): write opts + table, run work-items 0..n-1, read the

@@ -1,6 +1,8 @@
 """Command line front end for the render path.
 
     python -m raymarchcl_amd gen-gyroid --res 256 --out gyroid-256.vox
+    python -m raymarchcl_amd gen-terrain --res 256 --out terrain-256.vox
+    python -m raymarchcl_amd voxelize --stl bunny.stl --res 512 --ks 1 --out bunny-512.vox
     python -m raymarchcl_amd render --vox gyroid-256.vox --mat metal --width 1280 --height 720 \\
         --iter 16 --theta 135 --dist 2.25 --out frame.png
 
@@ -19,6 +21,14 @@ def main(argv=None):
     g.add_argument("--res", type=int, default=256)
     g.add_argument("--out", required=True)
     g.add_argument("--cpu", action="store_true", help="generate with numpy instead of the device kernel")
+    t = sub.add_parser("gen-terrain", help="write gen/make-terrain (generators.clj:44-60) as a .vox file")
+    t.add_argument("--res", type=int, default=256)
+    t.add_argument("--out", required=True)
+    v = sub.add_parser("voxelize", help="STL mesh -> .vox by vertex splatting (meshvoxel.clj voxelize / voxelize-ks)")
+    v.add_argument("--stl", required=True)
+    v.add_argument("--res", type=int, default=256)
+    v.add_argument("--ks", type=int, default=-1, help="cube half-size around every vertex; -1 = the vertex's own cell")
+    v.add_argument("--out", required=True)
     r = sub.add_parser("render", help="render one frame of a .vox volume to a PNG (test-render)")
     r.add_argument("--vox", required=True)
     r.add_argument("--out", default="foo.png")
@@ -46,6 +56,18 @@ def main(argv=None):
 
             with _native.Context(0) as ctx:
                 vox = ctx.make_gyroid_volume(args.res)
+        vio.save_volume(args.out, args.res, vox)
+        print(f"{args.out}: {args.res}^3, {int((vox > 0).sum())} filled voxels, {time.time() - t0:.2f} s")
+        return 0
+    if args.cmd in ("gen-terrain", "voxelize"):
+        from . import _native, meshvoxel
+
+        t0 = time.time()
+        with _native.Context(0) as ctx:
+            if args.cmd == "gen-terrain":
+                vox = ctx.make_terrain_volume(args.res)
+            else:
+                vox = ctx.voxelize_vertices(meshvoxel.load_mesh(args.stl), args.res, args.ks)
         vio.save_volume(args.out, args.res, vox)
         print(f"{args.out}: {args.res}^3, {int((vox > 0).sum())} filled voxels, {time.time() - t0:.2f} s")
         return 0

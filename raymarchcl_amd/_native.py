@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 # RAYMARCH_LIB: load (and build) another file of this directory instead, e.g. an A/B
 # variant built with extra flags by tools/ab_build.py; the product default is the name below
 LIB_PATH = os.path.join(HERE, os.path.basename(os.environ.get("RAYMARCH_LIB", "libraymarch_hip.so")))
-SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_stream.hip", "rm_api.hip", "rm_host.cpp"]
+SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_volgen.hip", "rm_stream.hip", "rm_api.hip", "rm_host.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 OPTS_BYTES = 544
@@ -25,7 +25,7 @@ TABLE_FLOATS = 0x4000 * 4
 EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_destroy",
     "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
-    "rm_make_gyroid_volume",
+    "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_selftest_prims",
@@ -111,6 +111,9 @@ def lib():
     L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
+    L.rm_make_terrain_volume.argtypes = [_vp, _i, _i, _i, _vp]
+    L.rm_voxelize_vertices.argtypes = [_vp, _vp, ctypes.c_longlong, _i, _i, _vp]
+    L.rm_make_heatmap_volume.argtypes = [_vp, _vp, _i, ctypes.c_double, _vp]
     L.rm_render_image.argtypes = [_vp, _vp, _vp, _vp, _i]
     L.rm_render_image_range.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i]
     L.rm_render_image_counted.argtypes = [_vp, _vp, _vp, _vp, _i, ctypes.POINTER(Counters)]
@@ -185,6 +188,36 @@ class Context:
         out = np.zeros(rx * ry * rz, dtype=np.uint8) if want_host_copy else None
         check(lib().rm_make_gyroid_volume(self._h, rx, ry, rz, out.ctypes.data if want_host_copy else None))
         self.vres = (rx, ry, rz)
+        return out
+
+    def make_terrain_volume(self, vres, want_host_copy=True):
+        """gen/make-terrain (generators.clj:44-60) on the device -> resident volume."""
+        rx, ry, rz = ((int(vres),) * 3 if isinstance(vres, (int, np.integer)) else tuple(int(v) for v in vres))
+        out = np.zeros(rx * ry * rz, dtype=np.uint8) if want_host_copy else None
+        check(lib().rm_make_terrain_volume(self._h, rx, ry, rz, out.ctypes.data if want_host_copy else None))
+        self.vres = (rx, ry, rz)
+        return out
+
+    def voxelize_vertices(self, vertices, res, ks=-1, want_host_copy=True):
+        """meshvoxel.clj voxelize (ks < 0) / voxelize-ks on the device -> resident res^3 volume."""
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+        res = int(res)
+        out = np.zeros(res ** 3, dtype=np.uint8) if want_host_copy else None
+        check(lib().rm_voxelize_vertices(self._h, v.ctypes.data if v.size else None, v.shape[0], res, int(ks),
+                                         out.ctypes.data if want_host_copy else None))
+        self.vres = (res, res, res)
+        return out
+
+    def make_heatmap_volume(self, argb, amp, want_host_copy=True):
+        """meshvoxel.clj make-heatmap on the device from a square ARGB image (uint32 [res, res])."""
+        a = np.ascontiguousarray(argb, dtype=np.uint32)
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError("argb must be a square 2-D array")
+        res = a.shape[0]
+        out = np.zeros(res ** 3, dtype=np.uint8) if want_host_copy else None
+        check(lib().rm_make_heatmap_volume(self._h, a.ctypes.data, res, float(amp),
+                                           out.ctypes.data if want_host_copy else None))
+        self.vres = (res, res, res)
         return out
 
     def set_stream(self, stream_ptr):

@@ -68,7 +68,7 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf;
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
   int phase_mode = 0;      // RAYMARCH_KERNEL=phases: chain / point rays / shading as three launches
@@ -452,6 +452,80 @@ int rm_make_gyroid_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out
   c->rx = rx; c->ry = ry; c->rz = rz;
   c->accel_iso = -1;
   return RM_OK;
+}
+
+// shared tail of the device-side volume producers: optional copy back, make resident
+static int adopt_generated(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out) {
+  const size_t bytes = (size_t)rx * ry * rz;
+  if (voxels_out)
+    HIP_TRY(hipMemcpyAsync(voxels_out, c->vox_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
+  c->rx = rx; c->ry = ry; c->rz = rz;
+  c->accel_iso = -1;
+  return RM_OK;
+}
+
+int rm_make_terrain_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  rc = check_res(rx, ry, rz);
+  if (rc) return rc;
+  if (rx < 4 || rz < 4) return fail(RM_EINVAL, "terrain needs rx, rz >= 4 (walls are 4 voxels thick)");
+  HIP_TRY(c->vox_buf.reserve((size_t)rx * ry * rz));
+  HIP_TRY(rmk::launch_terrain(c->stream, static_cast<uint8_t*>(c->vox_buf.p), rx, ry, rz));
+  return adopt_generated(c, rx, ry, rz, voxels_out);
+}
+
+int rm_voxelize_vertices(rm_ctx* c, const double* xyz, long long n_vertices, int res, int ks,
+                         uint8_t* voxels_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  rc = check_res(res, res, res);
+  if (rc) return rc;
+  if (n_vertices < 0 || (!xyz && n_vertices > 0)) return fail(RM_EINVAL, "bad vertex array");
+  if (ks > res) ks = res;
+  // mesh-scale (meshvoxel.clj:16-25): bounding box, largest extent, centring offsets --
+  // a min/max pass over data that arrives from the host anyway
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (long long i = 0; i < n_vertices; i++)
+    for (int k = 0; k < 3; k++) {
+      const double v = xyz[3 * i + k];
+      if (v != v) return fail(RM_EINVAL, "vertex %lld is NaN", i);
+      if (i == 0 || v < lo[k]) lo[k] = v;
+      if (i == 0 || v > hi[k]) hi[k] = v;
+    }
+  const double sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+  const double md = sx > sy ? (sx > sz ? sx : sz) : (sy > sz ? sy : sz);
+  if (n_vertices > 0 && !(md > 0.0)) return fail(RM_EINVAL, "degenerate mesh: zero extent");
+  const double size[3] = {sx, sy, sz};
+  double off[3] = {0, 0, 0};
+  for (int k = 0; k < 3; k++) off[k] = (0.5 * (double)res) * (1.0 - size[k] / md);
+  const double s = n_vertices > 0 ? (double)res / md : 1.0;
+  const size_t bytes = (size_t)res * res * res;
+  HIP_TRY(c->vox_buf.reserve(bytes));
+  if (n_vertices > 0) {
+    HIP_TRY(c->gen_buf.reserve((size_t)n_vertices * 24));
+    HIP_TRY(hipMemcpyAsync(c->gen_buf.p, xyz, (size_t)n_vertices * 24, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(rmk::launch_splat(c->stream, static_cast<uint8_t*>(c->vox_buf.p),
+                            static_cast<const double*>(c->gen_buf.p), n_vertices, lo, off, s, res, ks));
+  return adopt_generated(c, res, res, res, voxels_out);
+}
+
+int rm_make_heatmap_volume(rm_ctx* c, const uint32_t* argb, int res, double amp, uint8_t* voxels_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  rc = check_res(res, res, res);
+  if (rc) return rc;
+  if (!argb) return fail(RM_EINVAL, "argb is NULL");
+  if (amp != amp) return fail(RM_EINVAL, "amp is NaN");
+  HIP_TRY(c->vox_buf.reserve((size_t)res * res * res));
+  HIP_TRY(c->gen_buf.reserve((size_t)res * res * 4));
+  HIP_TRY(hipMemcpyAsync(c->gen_buf.p, argb, (size_t)res * res * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(rmk::launch_heatmap(c->stream, static_cast<uint8_t*>(c->vox_buf.p),
+                              static_cast<const uint32_t*>(c->gen_buf.p), res, amp));
+  return adopt_generated(c, res, res, res, voxels_out);
 }
 
 int rm_render_image(rm_ctx* c, const float* mc, const void* opts544, float* pixels, int n) {

@@ -62,6 +62,11 @@ hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                        uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
+// rm_volgen.hip: the other volume producers of the reference, on the device
+hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
+hipError_t launch_splat(hipStream_t st, uint8_t* d_out, const double* d_xyz, long long n,
+                        const double p[3], const double off[3], double s, int res, int ks);
+hipError_t launch_heatmap(hipStream_t st, uint8_t* d_out, const uint32_t* d_argb, int res, double amp);
 hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,
                         int n);
 }  // namespace rmk
