@@ -118,7 +118,11 @@ def main():
     from raymarchcl_amd import _native, multigpu
 
     if args.frames_in_flight <= 0:
-        args.frames_in_flight = 3 if world == 1 else 2
+        # measured: overlapping frames hides the ~0.4 ms tail of a launch (256^3: 3 streams
+        # -5 %), but with volumes far beyond the caches concurrent frames evict each other
+        # (512^3: +5 %, 1024^3: +7 %)
+        big = WORKLOADS[args.workload]["vres"] ** 3 > (64 << 20)
+        args.frames_in_flight = 1 if big else (3 if world == 1 else 2)
 
     _native.build()
     wl = WORKLOADS[args.workload]

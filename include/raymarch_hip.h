@@ -151,8 +151,10 @@ int rm_resolve_device(rm_ctx* ctx, const float* d_tiles_all, int parts, const vo
  * TRenderOpts.resolution.x.  This synchronous helper fetches the `iter` records
  * once and applies the same validation the host-buffer entry points do
  * (resolution, voxelRes against the resident volume, numLights), and notes each
- * record's isoVal; rm_frame_device refuses d_opts that were not checked.  Call
- * it again after rewriting the records in place. */
+ * record's isoVal; rm_frame_device refuses d_opts that were not checked.  It also
+ * builds the structures derived from the volume for the first record's isoVal
+ * (otherwise the first frame would).  Call it again after rewriting the records
+ * in place. */
 int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int width);
 
 /* Elapsed milliseconds of the RenderImage-pass kernels of the last
@@ -168,6 +170,11 @@ int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
  * value + smooth/flat normal terms; meaningful where value > iso).  Either
  * pointer may be NULL. */
 int rm_debug_get_accel(rm_ctx* ctx, int iso, uint8_t* dist_out, uint32_t* surf_out);
+/* Same for the 8 directional tables (csrc/rm_accel.hip oct8): oct_out = 8 * rx*ry*rz
+ * bytes, table o (bit 0/1/2 set = walking towards -x/-y/-z) holds per cell the edge of
+ * the largest cube of empty in-grid cells with that cell as its corner, extending in
+ * the walking direction (0 = hit cell, capped at 255). */
+int rm_debug_get_octants(rm_ctx* ctx, int iso, uint8_t* oct_out);
 
 /* ---- host-side parameter layer (no device needed) ------------------------
  * The reference builds its inputs in Clojure; a non-Python host gets the same

@@ -28,7 +28,7 @@ EXPORTS = [
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_selftest_prims",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
@@ -126,6 +126,7 @@ def lib():
     L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
     L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
     L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
+    L.rm_debug_get_octants.argtypes = [_vp, _i, _vp]
     _lib = L
     return L
 
@@ -299,6 +300,13 @@ class Context:
         surf = np.zeros(nvox, dtype=np.uint32)
         check(lib().rm_debug_get_accel(self._h, iso, dist.ctypes.data, surf.ctypes.data))
         return dist, surf
+
+    def debug_get_octants(self, iso):
+        """-> uint8 [8, rz, ry, rx]: the directional tables of the resident volume."""
+        rx, ry, rz = self.vres
+        out = np.zeros(8 * rx * ry * rz, dtype=np.uint8)
+        check(lib().rm_debug_get_octants(self._h, iso, out.ctypes.data))
+        return out.reshape(8, rz, ry, rx)
 
     def selftest_prims(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)

@@ -108,6 +108,88 @@ __global__ __launch_bounds__(256) void surf_kernel(const uint8_t* __restrict__ v
   }
 }
 
+// ---- oct8: directional empty-cube sizes ------------------------------------------
+// dist8 is limited by the nearest obstacle in ANY direction -- also the surface a
+// shadow ray, AO probe or reflection has just left.  oct8[o][q] (o = sign bits of the
+// walk direction, x | y<<1 | z<<2, bit set = negative) is the edge n of the largest
+// cube of empty in-grid cells that has q as its corner and extends AHEAD of the walk:
+// cells q + s*(i,j,k), 0 <= i,j,k < n.  A walk never moves against its direction
+// signs, so the samples it may skip are exactly those of dist8's rule with d := n
+// (n >= d always).  0 = hit cell, capped at 255.
+//
+// Built from a summed-volume table of the hit mask (box sum == 0 <=> box empty) by
+// bisection on n: 8 steps x 8 reads per (cell, octant).
+__global__ __launch_bounds__(256) void sat_x_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
+                                                    uint32_t* __restrict__ sat) {
+  // sat has (rx+1, ry+1, rz+1) entries; entry (x,y,z) = number of hit cells in [0,x) x [0,y) x [0,z)
+  const long long rows = (long long)(d.ry + 1) * (d.rz + 1);
+  const long long sx = d.rx + 1;
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
+       r += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(r % (d.ry + 1)), z = (int)(r / (d.ry + 1));
+    uint32_t* row = sat + r * sx;
+    uint32_t acc = 0;
+    row[0] = 0;
+    if (y == 0 || z == 0) {
+      for (int x = 1; x <= d.rx; x++) row[x] = 0;
+      continue;
+    }
+    const uint8_t* src = vox + ((long long)(z - 1) * d.ry + (y - 1)) * d.rx;
+    for (int x = 1; x <= d.rx; x++) {
+      acc += src[x - 1] > iso ? 1u : 0u;
+      row[x] = acc;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sat_axis_kernel(uint32_t* __restrict__ sat, Dim d, int axis) {
+  const long long sx = d.rx + 1, sy = d.ry + 1, sz = d.rz + 1;
+  const long long lines = axis == 1 ? sx * sz : sx * sy;
+  for (long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x; l < lines;
+       l += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(l % sx);
+    const long long o = l / sx;  // z (axis 1) or y (axis 2)
+    long long base, stride;
+    int len;
+    if (axis == 1) { base = (o * sy) * sx + x; stride = sx; len = (int)sy; }
+    else { base = o * sx + x; stride = sx * sy; len = (int)sz; }
+    uint32_t acc = 0;
+    for (int k = 0; k < len; k++) {
+      acc += sat[base + k * stride];
+      sat[base + k * stride] = acc;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t sat_box(const uint32_t* __restrict__ sat, const Dim& d, int x0,
+                                            int x1, int y0, int y1, int z0, int z1) {
+  // hit cells in [x0,x1) x [y0,y1) x [z0,z1)
+  const long long sx = d.rx + 1, sxy = sx * (d.ry + 1);
+#define RM_S(X, Y, Z) sat[(long long)(Z) * sxy + (long long)(Y) * sx + (X)]
+  return RM_S(x1, y1, z1) - RM_S(x0, y1, z1) - RM_S(x1, y0, z1) - RM_S(x1, y1, z0) + RM_S(x0, y0, z1) +
+         RM_S(x0, y1, z0) + RM_S(x1, y0, z0) - RM_S(x0, y0, z0);
+#undef RM_S
+}
+__global__ __launch_bounds__(256) void oct_kernel(const uint32_t* __restrict__ sat, Dim d,
+                                                  uint8_t* __restrict__ out8) {
+  const long long total = (long long)d.rx * d.ry * d.rz;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total * 8;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(i / total);
+    const long long c = i % total;
+    const int x = (int)(c % d.rx), y = (int)((c / d.rx) % d.ry), z = (int)(c / ((long long)d.rx * d.ry));
+    const bool nx = o & 1, ny = o & 2, nz = o & 4;
+    // room to the grid edge ahead, per axis (cells including q itself)
+    int hi = min(255, min(nx ? x + 1 : d.rx - x, min(ny ? y + 1 : d.ry - y, nz ? z + 1 : d.rz - z)));
+    int lo = 0;  // largest n known empty
+    while (lo < hi) {
+      const int n = (lo + hi + 1) >> 1;
+      const int x0 = nx ? x - n + 1 : x, y0 = ny ? y - n + 1 : y, z0 = nz ? z - n + 1 : z;
+      if (sat_box(sat, d, x0, x0 + n, y0, y0 + n, z0, z0 + n) == 0) lo = n;
+      else hi = n - 1;
+    }
+    out8[i] = (uint8_t)lo;
+  }
+}
+
 // The benchmark volume on the device (reference generators.clj:18-42 fills it on one
 // JVM thread, minutes for 512^3).  Same formula in binary64; cos/sin come from the
 // device math library, so a voxel whose value sits within an ulp of a threshold may
@@ -139,6 +221,18 @@ hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz)
   const long long total = (long long)rx * ry * rz;
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
   gyroid_kernel<<<blocks, 256, 0, st>>>(d_out, d);
+  return hipGetLastError();
+}
+
+hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
+                         uint8_t* d_dist9, uint32_t* d_sat) {
+  const Dim d{rx, ry, rz};
+  const long long total = (long long)rx * ry * rz;
+  auto blocks_for = [](long long n) { return (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256); };
+  sat_x_kernel<<<blocks_for((long long)(ry + 1) * (rz + 1)), 256, 0, st>>>(d_vox, d, iso, d_sat);
+  sat_axis_kernel<<<blocks_for((long long)(rx + 1) * (rz + 1)), 256, 0, st>>>(d_sat, d, 1);
+  sat_axis_kernel<<<blocks_for((long long)(rx + 1) * (ry + 1)), 256, 0, st>>>(d_sat, d, 2);
+  oct_kernel<<<blocks_for(total * 8), 256, 0, st>>>(d_sat, d, d_dist9 + total);
   return hipGetLastError();
 }
 

@@ -68,7 +68,9 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf;
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf;
+  bool use_octants = false, force_octants = false;
+  unsigned int oct_stride = 0;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
   int phase_mode = 0;      // RAYMARCH_KERNEL=phases: chain / point rays / shading as three launches
@@ -127,14 +129,29 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   if ((long long)c->ry * c->rz >= (1 << 24) || c->rx >= (1 << 24)) return RM_OK;
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
   if (c->accel_iso != iso) {
-    HIP_TRY(c->dist_buf.reserve(vox));
+    // directional tables behind dist8: by default only while all 9 tables fit the 256 MB
+    // Infinity Cache (measured: 256^3 -10 % frame time, 512^3 +6 %: the eight-fold working
+    // set then misses more than the longer skips save); RAYMARCH_OCTANTS=1 forces them
+    // for anything that stays within 32-bit offsets
+    const bool oct = c->use_octants && vox * 9 < 0xffffffffull &&
+                     (c->force_octants || vox * 9 <= (256ull << 20));
+    HIP_TRY(c->dist_buf.reserve(oct ? vox * 9 : vox));
     HIP_TRY(c->tmp_buf.reserve(vox));
     HIP_TRY(c->surf_buf.reserve(vox * 4));
     HIP_TRY(rmk::build_accel(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso,
                              static_cast<uint8_t*>(c->dist_buf.p), static_cast<uint8_t*>(c->tmp_buf.p),
                              static_cast<uint32_t*>(c->surf_buf.p)));
+    c->oct_stride = 0;
+    if (oct) {
+      const size_t sat = (size_t)(c->rx + 1) * (c->ry + 1) * (c->rz + 1) * 4;
+      HIP_TRY(c->sat_buf.reserve(sat));
+      HIP_TRY(rmk::build_octants(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso,
+                                 static_cast<uint8_t*>(c->dist_buf.p), static_cast<uint32_t*>(c->sat_buf.p)));
+      c->oct_stride = (unsigned int)vox;
+    }
     c->accel_iso = iso;
   }
+  out->oct_stride = c->oct_stride;
   out->dist = static_cast<const uint8_t*>(c->dist_buf.p);
   out->surf = static_cast<const uint32_t*>(c->surf_buf.p);
   return RM_OK;
@@ -346,6 +363,9 @@ int rm_create(int device_id, rm_ctx** out) {
   c->stream = c->own_stream;
   const char* na = getenv("RAYMARCH_NO_ACCEL");
   c->use_accel = !(na && na[0] == '1');
+  const char* oc = getenv("RAYMARCH_OCTANTS");
+  c->use_octants = !(oc && oc[0] == '0');  // directional tables: on unless RAYMARCH_OCTANTS=0
+  c->force_octants = oc && oc[0] == '1';   // ... =1: also for volumes beyond the cache-fit limit
   const char* km = getenv("RAYMARCH_KERNEL");
   c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
   c->stream_mode = km && strcmp(km, "stream") == 0;  // experimental task-queue pipeline
@@ -634,6 +654,11 @@ int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int wid
   records_same_as_prev(recs.data(), iter, &c->dev_same);
   c->dev_recs = recs;
   c->dev_iso_src = d_opts;
+  // build the derived structures of the (first) hit threshold now, not inside the first frame
+  rmk::Accel accel;
+  rc = ensure_accel(c, recs[0].isoVal, &accel);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }
 
@@ -689,6 +714,22 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
   if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
   if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+int rm_debug_get_octants(rm_ctx* c, int iso, uint8_t* oct_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (iso < 0 || iso > 255 || !oct_out) return fail(RM_EINVAL, "bad argument");
+  rmk::Accel accel;
+  rc = ensure_accel(c, iso, &accel);
+  if (rc) return rc;
+  if (!accel.dist || !accel.oct_stride)
+    return fail(RM_ESTATE, "directional tables are not built (disabled, or volume too large)");
+  const size_t vox = (size_t)c->rx * c->ry * c->rz;
+  HIP_TRY(hipMemcpyAsync(oct_out, accel.dist + vox, vox * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }

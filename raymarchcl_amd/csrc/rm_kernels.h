@@ -16,6 +16,8 @@ void dump_work_stats();  // no-op unless built with -DRM_WORK_STATS
 struct Accel {  // nullptrs = not available: the kernels then run the plain fixed-step march
   const uint8_t* dist = nullptr;
   const uint32_t* surf = nullptr;
+  // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
+  unsigned int oct_stride = 0;
 };
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
@@ -61,6 +63,10 @@ hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d
 // d_tmp is scratch of the volume's size.
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                        uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf);
+// the 8 directional tables behind dist8 (d_dist9 = 9 * volume bytes, table 0 = dist8 itself);
+// d_sat is scratch of (rx+1)(ry+1)(rz+1) uint32
+hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
+                         uint8_t* d_dist9, uint32_t* d_sat);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // rm_volgen.hip: the other volume producers of the reference, on the device
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);

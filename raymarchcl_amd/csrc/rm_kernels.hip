@@ -25,7 +25,7 @@
 // debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
 // over all lanes: samples, outer marches, their turns, filtered turns, voxel walks,
 // dist8 fetches, samples advanced, AO loops.  rmk::dump_work_stats() prints and resets.
-__device__ unsigned long long g_work_stats[16];
+__device__ unsigned long long g_work_stats[48];
 #endif
 
 namespace {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
     const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
-    int tile_stride, int tiles_per_part, int pp_log2, int bpr) {
+    int tile_stride, int tiles_per_part, int pp_log2, int bpr, unsigned int oct_stride) {
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
   const int pass0 = blockIdx.y * pp;
@@ -147,17 +147,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   const int pix = zy * 8 + zx;  // 0..63 within the tile, row-major 8x8
   const int id = lane_pixel((int)tile, pix, resx, g.tiles_x, n, 0, n);
   if (id < 0) return;
-  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32};
+  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32, oct_stride};
   rmk::Tracer<false, ACCEL> tr(sc);
   if (pp > 1) tr.set_pass(mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts_all[pass].time);
   const rmk::v3 col = tr.shade(id);
   staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
 #ifdef RM_WORK_STATS
   {
-    const unsigned int v[13] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
-                                tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est,
-                                tr.wv_walk_ao, tr.ws_lookups_ao};
-    for (int k = 0; k < 13; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
+    unsigned int v[32] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
+                          tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
+    for (int k = 0; k < 4; k++) {
+      v[11 + k] = tr.ws_k_walks[k];
+      v[15 + k] = tr.ws_k_fetch[k];
+      v[19 + k] = tr.ws_k_slots[k];
+    }
+    for (int k = 0; k < 6; k++) v[23 + k] = tr.ws_dhist[k];
+    v[29] = tr.ws_adds_hit; v[30] = tr.ws_adds_nohit; v[31] = tr.ws_adds_lazy;
+    for (int k = 0; k < 32; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
   }
 #endif
 }
@@ -443,7 +449,7 @@ int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
 void dump_work_stats() {
 #ifdef RM_WORK_STATS
-  unsigned long long h[16] = {0};
+  unsigned long long h[48] = {0};
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
   const double n = h[0] ? (double)h[0] : 1.0;
@@ -454,11 +460,20 @@ void dump_work_stats() {
                   "filtered turns %.1f%%, estimate turns %.1f%%\n",
           100.0 * h[5] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[9] ? h[9] : 1),
           100.0 * (h[2] - h[3]) / (h[10] ? h[10] : 1));
-  fprintf(stderr, "[work stats] walk loop split: AO probes %.2f fetches/sample in %.1f%% of the lane-slots at "
-                  "%.1f%% utilisation; marches %.2f fetches/sample at %.1f%%\n",
-          h[12] / n, 100.0 * h[11] / (h[8] ? h[8] : 1), 100.0 * h[12] / (h[11] ? h[11] : 1),
-          (h[5] - h[12]) / n, 100.0 * (h[5] - h[12]) / (h[8] - h[11] ? h[8] - h[11] : 1));
-  unsigned long long z[16] = {0};
+  static const char* kind[4] = {"primary march", "reflection march", "shadow march", "AO probe"};
+  for (int k = 0; k < 4; k++)
+    fprintf(stderr, "[work stats]   %-16s %.2f walks/sample, %.1f fetches/walk, %.1f%% of the walk lane-slots at "
+                    "%.1f%% utilisation\n",
+            kind[k], h[11 + k] / n, (double)h[15 + k] / (h[11 + k] ? h[11 + k] : 1),
+            100.0 * h[19 + k] / (h[8] ? h[8] : 1), 100.0 * h[15 + k] / (h[19 + k] ? h[19 + k] : 1));
+  fprintf(stderr, "[work stats] fetched dist8 values: hit %.1f%%, 1: %.1f%%, 2: %.1f%%, 3: %.1f%%, 4-7: %.1f%%, "
+                  "8+: %.1f%%\n",
+          100.0 * h[23] / h[5], 100.0 * h[24] / h[5], 100.0 * h[25] / h[5], 100.0 * h[26] / h[5],
+          100.0 * h[27] / h[5], 100.0 * h[28] / h[5]);
+  fprintf(stderr, "[work stats] samples advanced per sample: %.1f in walks that hit, %.1f in walks that do not "
+                  "(%.1f of them after the walk's last fetch with value <= 1)\n",
+          h[29] / n, h[30] / n, h[31] / n);
+  unsigned long long z[48] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
 #endif
 }
@@ -519,16 +534,16 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
   float4* st4 = reinterpret_cast<float4*>(staging);
   if (accel.dist && accel.surf)
     switch (min_waves) {
-      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
-      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
-      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
-      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
-      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
-      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr); break;
+      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
+      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
+      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
+      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
+      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
+      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
     }
   else
     render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
-                                                         n, tile_first, tile_stride, tpp, pp_log2, bpr);
+                                                         n, tile_first, tile_stride, tpp, pp_log2, bpr, 0u);
   return hipGetLastError();
 }
 

@@ -54,6 +54,7 @@ struct Scene {
   const RmOpts* __restrict__ o;
   const uint8_t* __restrict__ dist;   // rm_accel.hip dist8, or nullptr
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
+  unsigned int oct_stride = 0;        // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
 };
 
 // ---- leaf routines shared by the straight (Tracer) and wave-scheduled
@@ -142,7 +143,7 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // j = 1 + floor(0.98 * (d-1) / s)   (inv_s = 0.98 / s; the 2 % absorb the <= 0.01
 // cell of accumulated rounding drift and the rounding of p*res).
 RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
-                     float inv_s, int* cell_out) {
+                     float inv_s, int* cell_out, unsigned int table_off = 0, unsigned int* dhist = nullptr) {
   const int qx = rmd::convert_int_sat(p.x * (float)o.voxelRes[0]);
   const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
   const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
@@ -151,7 +152,11 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   // derived structures when ry*rz < 2^24 and rx < 2^24) and an unsigned 32-bit offset
   const unsigned cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
                                  (unsigned)o.voxelRes[0]) + (unsigned)qx;
-  const int d = dist8[cell];
+  const int d = dist8[cell + table_off];
+  if (dhist) {  // stats build only
+    dhist[d < 4 ? d : (d < 8 ? 4 : 5)]++;
+    dhist[6] = (unsigned)d;
+  }
   if (d == 0) {
     *cell_out = (int)cell;
     return 1;
@@ -209,8 +214,11 @@ struct Tracer {
                ws_probes = 0, ws_steps = 0;
   // lane-slots a wavefront spends in a loop (64 per trip, charged to its first active lane)
   unsigned int wv_walk = 0, wv_filt = 0, wv_est = 0;
-  unsigned int wv_walk_ao = 0, ws_lookups_ao = 0;  // the share of the AO probes in wv_walk / ws_lookups
-  bool ws_in_ao = false;
+  // split by what the walk belongs to: 0 primary march, 1 reflection march, 2 shadow march, 3 AO probe
+  int ws_kind = 0;
+  unsigned int ws_k_walks[4] = {0, 0, 0, 0}, ws_k_fetch[4] = {0, 0, 0, 0}, ws_k_slots[4] = {0, 0, 0, 0};
+  unsigned int ws_dhist[7] = {0, 0, 0, 0, 0, 0, 0};  // fetched dist8 value: 0 (hit), 1, 2, 3, 4-7, 8+; [6] = last value
+  unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
   RM_DEV unsigned int wave_slots() {
     const unsigned long long act = __ballot(1);
     return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? 64u : 0u;
@@ -308,21 +316,46 @@ struct Tracer {
         const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
                               __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
+        // directional table of this walk (a walk never moves against the signs of delta)
+        unsigned int table_off = 0;
+        if (sc.oct_stride) {
+          const unsigned int oct = (delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u);
+          table_off = (oct + 1u) * sc.oct_stride;
+        }
         RM_WS(ws_walks++);
+        RM_WS(ws_k_walks[ws_kind]++);
         (void)s;
         // the loop holds nothing but the walk: a lane that finds its hit waits for the
         // others and all hits are then evaluated together (inside the loop the compiler
         // runs the hit code once per trip in which any lane finishes)
         int cell = 0, r;
+#ifdef RM_WORK_STATS
+        const int ws_steps0 = steps;
+        int ws_klast = 0;
+#endif
         do {
           RM_WS(ws_lookups++);
           RM_WS(wv_walk += wave_slots());
-          RM_WS(wv_walk_ao += ws_in_ao ? wave_slots() : 0u);
-          RM_WS(ws_lookups_ao += ws_in_ao ? 1u : 0u);
+          RM_WS(ws_k_slots[ws_kind] += wave_slots());
+          RM_WS(ws_k_fetch[ws_kind]++);
           RM_WS(ws_steps += (unsigned)steps);
-          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell);
+#ifdef RM_WORK_STATS
+          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist);
+#else
+          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off);
+#endif
           RM_WS(ws_steps -= (unsigned)steps);
+#ifdef RM_WORK_STATS
+          if (ws_dhist[6] <= 1u && r == 0) ws_klast = ws_steps0 - steps;
+#endif
         } while (r == 0);
+#ifdef RM_WORK_STATS
+        if (r == 1) ws_adds_hit += (unsigned)(ws_steps0 - steps);
+        else {
+          ws_adds_nohit += (unsigned)(ws_steps0 - steps);
+          ws_adds_lazy += (unsigned)(ws_steps0 - steps - ws_klast);
+        }
+#endif
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
           nrm = surf_normal(w, smooth);
@@ -501,7 +534,12 @@ struct Tracer {
   // renderer.cl:292-301
   RM_DEV float shadow_term(v3 p, v3 ldir, float lmax) {
     Hit h{};
+#ifdef RM_WORK_STATS
+    const int ws_saved = ws_kind;
+    ws_kind = 2;
+#endif
     march(p, ldir, h, lmax, sc.o->shadowIter, false);
+    RM_WS(ws_kind = ws_saved);
     return rmd::step_cl(lmax, h.distance);
   }
   RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) { return schlick_of(r0, smooth, n, view); }
@@ -524,9 +562,12 @@ struct Tracer {
       const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, normal));
       float sd, scode;
       v3 nn;
-      RM_WS(ws_in_ao = true);
+#ifdef RM_WORK_STATS
+      const int ws_saved = ws_kind;
+      ws_kind = 3;
+#endif
       scene_distance(mads(n, d, pos), n, o.maxVoxelIter / 2, false, sd, scode, nn);
-      RM_WS(ws_in_ao = false);
+      RM_WS(ws_kind = ws_saved);
       ao *= 1.0f - rmd::fmax_cl((d - sd) * o.aoAmp / d, 0.0f);
     }
     return ao;
@@ -563,6 +604,7 @@ struct Tracer {
   // one reflection bounce: renderer.cl:383-405
   RM_DEV v3 bounce_colour(const Sample& s, v3 ro, v3 rdir, Hit& h) {
     const RmOpts& o = *sc.o;
+    RM_WS(ws_kind = 1);
     march(ro, rdir, h, o.maxDist, o.maxIter, false);
     v3 col;
     if (h.objectID < 0) {
@@ -577,7 +619,9 @@ struct Tracer {
   RM_DEV v3 sample_colour(const Sample& s, v3 ro, v3 rdir) {
     const RmOpts& o = *sc.o;
     Hit h{};
+    RM_WS(ws_kind = 0);
     march(ro, rdir, h, o.maxDist, o.maxIter, true);
+    RM_WS(ws_kind = 0);
     v3 col;
     if (h.distance >= o.maxDist) {
       col = sky(rdir);

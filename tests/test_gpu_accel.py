@@ -68,3 +68,44 @@ def test_device_gyroid_generator_matches_host(native):
         ctx.make_gyroid_volume(64, want_host_copy=False)
         px, _ = ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
         assert np.isfinite(px).all() and px.any()
+
+
+def _oct_reference(hit):
+    """Largest empty cube ahead of every cell for all 8 sign combinations, by brute force:
+    n(q) = #{n >= 1 : the n^3 box with corner q is inside the grid and holds no hit cell}
+    (box emptiness is monotone in n), boxes summed with a padded cumulative table."""
+    rz, ry, rx = hit.shape
+    out = np.zeros((8, rz, ry, rx), np.uint8)
+    for o in range(8):
+        flips = tuple(ax for ax, bit in ((2, 1), (1, 2), (0, 4)) if o & bit)  # x=bit0, y=bit1, z=bit2
+        h = np.flip(hit, flips) if flips else hit
+        sat = np.zeros((rz + 1, ry + 1, rx + 1), np.int64)
+        sat[1:, 1:, 1:] = h.astype(np.int64).cumsum(0).cumsum(1).cumsum(2)
+        n_tab = np.zeros((rz, ry, rx), np.int32)
+        z, y, x = np.meshgrid(np.arange(rz), np.arange(ry), np.arange(rx), indexing="ij")
+        for n in range(1, min(255, max(rx, ry, rz)) + 1):
+            ok = (z + n <= rz) & (y + n <= ry) & (x + n <= rx)
+            if not ok.any():
+                break
+            z1, y1, x1 = np.minimum(z + n, rz), np.minimum(y + n, ry), np.minimum(x + n, rx)
+            s = (sat[z1, y1, x1] - sat[z, y1, x1] - sat[z1, y, x1] - sat[z1, y1, x] + sat[z, y, x1]
+                 + sat[z, y1, x] + sat[z1, y, x] - sat[z, y, x])
+            n_tab += (ok & (s == 0))
+        t = n_tab.astype(np.uint8)
+        out[o] = np.flip(t, flips) if flips else t
+    return out
+
+
+@pytest.mark.parametrize("kind,vres,iso", [("gyroid", 32, 32), ("gyroid-crop", (64, 40, 48), 32),
+                                           ("blobs", 32, 100), ("empty", 16, 32), ("solid", 16, 32)])
+def test_directional_tables(gpu_ctx, kind, vres, iso):
+    vox = scenes.volume(kind, vres)
+    rx, ry, rz = (vres,) * 3 if isinstance(vres, int) else vres
+    gpu_ctx.set_volume(vox, (rx, ry, rz))
+    got = gpu_ctx.debug_get_octants(iso)
+    want = _oct_reference(vox.reshape(rz, ry, rx) > iso)
+    assert np.array_equal(got, want)
+    # every directional value is at least the undirected one (the centred cube of dist8
+    # contains a cube of edge d ahead of the cell)
+    dist, _ = gpu_ctx.debug_get_accel(iso)
+    assert (got >= dist.reshape(1, rz, ry, rx)).all()

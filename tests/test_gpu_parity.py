@@ -218,9 +218,11 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
                 {"RAYMARCH_KERNEL": "split"}, {"RAYMARCH_KERNEL": "split", "RAYMARCH_SPLIT_WAVES": "4,5"},
                 {"RAYMARCH_KERNEL": "straight", "RAYMARCH_STRAIGHT_WAVES": "3"},
                 {"RAYMARCH_KERNEL": "straight", "RAYMARCH_STRAIGHT_WAVES": "5"},
-                {"RAYMARCH_NO_ACCEL": "1"}, {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVE_BLOCKS": "3"}):
+                {"RAYMARCH_NO_ACCEL": "1"}, {"RAYMARCH_KERNEL": "wave", "RAYMARCH_WAVE_BLOCKS": "3"},
+                {"RAYMARCH_OCTANTS": "0"}, {"RAYMARCH_OCTANTS": "0", "RAYMARCH_PASS_PACK": "0"}):
         for k in ("RAYMARCH_WAVES", "RAYMARCH_KERNEL", "RAYMARCH_NO_ACCEL", "RAYMARCH_WAVE_BLOCKS",
-                  "RAYMARCH_BATCH_SAMPLES", "RAYMARCH_STRAIGHT_WAVES", "RAYMARCH_SPLIT_WAVES", "RAYMARCH_PASS_PACK"):
+                  "RAYMARCH_BATCH_SAMPLES", "RAYMARCH_STRAIGHT_WAVES", "RAYMARCH_SPLIT_WAVES", "RAYMARCH_PASS_PACK",
+                  "RAYMARCH_OCTANTS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
