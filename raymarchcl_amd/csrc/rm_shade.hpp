@@ -423,12 +423,11 @@ struct Tracer {
   // true when the estimate at distance t certainly returns the ground/sky term
   // (renderer.cl:214 condition false) -- ground distance `g` = res.x there
   RM_DEV bool surely_no_walk(const BoxFilter& f, float t, float g) {
-    if (!f.ok) return false;
-    const float m = f.slack + 8e-6f * __builtin_fabsf(t);
-    return (g <= 0.0f)                   // entry distance is >= 0 or -1: never < g
-           | (f.far0 - t < -m)           // box entirely behind: b < 0 <= a
-           | (f.far0 - f.near0 < -m)     // the line misses the box: b < a
-           | (f.near0 - t > g + m);      // entry farther than the ground term
+    // (straight-line on purpose: this sits in the hottest loop of the march)
+    const float m = __builtin_fmaf(__builtin_fabsf(t), 8e-6f, f.slack);
+    return f.ok & ((g <= 0.0f)                              // entry distance is >= 0 or -1: never < g
+                   | (fminf(f.far0 - t, f.far0 - f.near0) < -m)  // box entirely behind (b < 0 <= a) or missed (b < a)
+                   | (f.near0 - t > g + m));                // entry farther than the ground term
   }
   // true when the position at distance t is certainly inside the clip box and the ground
   // term is positive by a margin: the reference's slab test returns exactly +0 < g
@@ -449,7 +448,6 @@ struct Tracer {
     // large majority -- just remember that they were last; `last_t` is the distance
     // the surviving position was computed at.
     float last_t = dist, scode = 0.0f;
-    bool last_filtered = false, any = false;
     // Two nested loops instead of the reference's one: the inner loop runs a lane
     // through consecutive turns whose estimate is certainly the ground / sky term
     // (cheap, ~85 % of all turns) WITHOUT waiting for the other lanes; the outer
@@ -458,42 +456,52 @@ struct Tracer {
     // full walk in almost every turn because some lane always needed one; now it
     // pays one per round, and a ray has only 2-3 such turns.  Per lane the sequence
     // of operations is unchanged.
-    bool finished = false;
-    while (!finished) {
-      bool need_estimate = false;
+    // (Loop state is one int per lane, not several bools: the compiler keeps bools
+    // that live across a divergent loop as lane masks and spends three scalar
+    // instructions per flag and turn on them.)
+    //   why: 1 = this turn needs the real estimate, 2 = out of turns,
+    //        3 = stopped in a filtered turn, 4 = stopped in an estimated turn
+    const int turns0 = maxSteps;
+    int why;
+    int last_kind = 0;  // 1: the last executed turn took the real estimate
+    for (;;) {
       float g = 0.0f;
-      while (true) {
-        if (--maxSteps < 0) { finished = true; break; }
-        last_t = dist;
-        any = true;
-        const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
-        g = h < 1e5f ? h : 1e5f;
-        RM_WS(ws_iters++);
-        RM_WS(wv_filt += wave_slots());
-        if (COUNT || !surely_no_walk(flt, dist, g)) { need_estimate = true; break; }
-        RM_WS(ws_filtered++);
-        scode = h < 1e5f ? h : -1.0f;
-        last_filtered = true;
-        if (__builtin_fabsf(g) <= o.eps || dist >= maxDist) { finished = true; break; }
-        dist += g;
+      why = 2;
+      if (maxSteps > 0) {
+        // one exit: a turn either continues (filtered, not converged, turns left) or not
+        bool nw, go;
+        do {
+          maxSteps--;
+          last_t = dist;
+          const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
+          g = h < 1e5f ? h : 1e5f;
+          RM_WS(ws_iters++);
+          RM_WS(wv_filt += wave_slots());
+          nw = !COUNT && surely_no_walk(flt, dist, g);
+          RM_WS(ws_filtered += nw ? 1u : 0u);
+          go = nw & !((__builtin_fabsf(g) <= o.eps) | (dist >= maxDist));
+          dist = go ? dist + g : dist;
+        } while (go & (maxSteps > 0));
+        why = go ? 2 : (nw ? 3 : 1);
+        if (nw) last_kind = 0;
       }
-      if (need_estimate) {
-        float sd;
-        RM_WS(wv_est += wave_slots());
-        const bool inside = !COUNT && surely_inside(flt, dist, g);
-        scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
-        last_filtered = false;
-        if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) finished = true;
-        else dist += sd;
-      }
+      if (why != 1) break;
+      float sd;
+      RM_WS(wv_est += wave_slots());
+      const bool inside = !COUNT && surely_inside(flt, dist, g);
+      scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
+      last_kind = 1;
+      if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
+      dist += sd;
     }
-    if (any) {
+    if (maxSteps != turns0) {  // at least one turn: renderer.cl:244-246 values of the last one
       r.pos = mads(rdir, last_t, ro);
-      r.objectID = rmd::f2i(scode);
-      if (last_filtered) {  // renderer.cl:212 for the ground / sky term
-        const float g = (rdir.y * last_t + ro.y) + o.groundY;
-        r.normal = (g < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;
+      if (last_kind == 0) {  // renderer.cl:211-212 for the ground / sky term
+        const float h = (rdir.y * last_t + ro.y) + o.groundY;
+        scode = h < 1e5f ? h : -1.0f;
+        r.normal = (h < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;
       }
+      r.objectID = rmd::f2i(scode);
     }
     if (dist >= maxDist) {
       r.pos = mads(rdir, dist, ro);
