@@ -68,7 +68,7 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf;
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf, lin_buf;
   bool use_octants = false, force_octants = false;
   unsigned int oct_stride = 0;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
@@ -135,20 +135,35 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     // for anything that stays within 32-bit offsets
     const bool oct = c->use_octants && vox * 9 < 0xffffffffull &&
                      (c->force_octants || vox * 9 <= (256ull << 20));
-    HIP_TRY(c->dist_buf.reserve(oct ? vox * 9 : vox));
+    const int tables = oct ? 9 : 1;
+#if RM_BRICKS
+    // tables are built row-major in lin_buf, then re-laid in 8x4x4 bricks
+    const size_t bb = (size_t)rmk::bricked_bytes(c->rx, c->ry, c->rz);
+    HIP_TRY(c->lin_buf.reserve(vox * tables));
+    HIP_TRY(c->dist_buf.reserve(bb * tables));
+    uint8_t* lin = static_cast<uint8_t*>(c->lin_buf.p);
+#else
+    HIP_TRY(c->dist_buf.reserve(vox * tables));
+    uint8_t* lin = static_cast<uint8_t*>(c->dist_buf.p);
+#endif
     HIP_TRY(c->tmp_buf.reserve(vox));
     HIP_TRY(c->surf_buf.reserve(vox * 4));
-    HIP_TRY(rmk::build_accel(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso,
-                             static_cast<uint8_t*>(c->dist_buf.p), static_cast<uint8_t*>(c->tmp_buf.p),
-                             static_cast<uint32_t*>(c->surf_buf.p)));
+    HIP_TRY(rmk::build_accel(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso, lin,
+                             static_cast<uint8_t*>(c->tmp_buf.p), static_cast<uint32_t*>(c->surf_buf.p)));
     c->oct_stride = 0;
     if (oct) {
       const size_t sat = (size_t)(c->rx + 1) * (c->ry + 1) * (c->rz + 1) * 4;
       HIP_TRY(c->sat_buf.reserve(sat));
-      HIP_TRY(rmk::build_octants(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso,
-                                 static_cast<uint8_t*>(c->dist_buf.p), static_cast<uint32_t*>(c->sat_buf.p)));
+      HIP_TRY(rmk::build_octants(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso, lin,
+                                 static_cast<uint32_t*>(c->sat_buf.p)));
       c->oct_stride = (unsigned int)vox;
     }
+#if RM_BRICKS
+    for (int t = 0; t < tables; t++)
+      HIP_TRY(rmk::launch_brick(c->stream, lin + (size_t)t * vox, c->rx, c->ry, c->rz,
+                                static_cast<uint8_t*>(c->dist_buf.p) + (size_t)t * bb, true));
+    if (oct) c->oct_stride = (unsigned int)bb;
+#endif
     c->accel_iso = iso;
   }
   out->oct_stride = c->oct_stride;
@@ -712,7 +727,15 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
   rc = ensure_accel(c, iso, &accel);
   if (rc) return rc;
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
+#if RM_BRICKS
+  if (dist_out) {  // what the kernels read, converted back to row-major
+    HIP_TRY(rmk::launch_brick(c->stream, static_cast<uint8_t*>(c->tmp_buf.p), c->rx, c->ry, c->rz,
+                              const_cast<uint8_t*>(accel.dist), false));
+    HIP_TRY(hipMemcpyAsync(dist_out, c->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
+  }
+#else
   if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
+#endif
   if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
@@ -729,7 +752,16 @@ int rm_debug_get_octants(rm_ctx* c, int iso, uint8_t* oct_out) {
   if (!accel.dist || !accel.oct_stride)
     return fail(RM_ESTATE, "directional tables are not built (disabled, or volume too large)");
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
+#if RM_BRICKS
+  for (int t = 0; t < 8; t++) {
+    HIP_TRY(rmk::launch_brick(c->stream, static_cast<uint8_t*>(c->tmp_buf.p), c->rx, c->ry, c->rz,
+                              const_cast<uint8_t*>(accel.dist) + (size_t)(t + 1) * accel.oct_stride, false));
+    HIP_TRY(hipMemcpyAsync(oct_out + (size_t)t * vox, c->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+#else
   HIP_TRY(hipMemcpyAsync(oct_out, accel.dist + vox, vox * 8, hipMemcpyDeviceToHost, c->stream));
+#endif
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }

@@ -13,6 +13,10 @@ inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / p
 int tiles_total(int resx, int n);
 void dump_work_stats();  // no-op unless built with -DRM_WORK_STATS
 
+#ifndef RM_BRICKS
+#define RM_BRICKS 0  // see rm_shade.hpp
+#endif
+
 struct Accel {  // nullptrs = not available: the kernels then run the plain fixed-step march
   const uint8_t* dist = nullptr;
   const uint32_t* surf = nullptr;
@@ -67,6 +71,10 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
 // d_sat is scratch of (rx+1)(ry+1)(rz+1) uint32
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                          uint8_t* d_dist9, uint32_t* d_sat);
+// RM_BRICKS layout of a byte table (8x4x4-cell bricks of 128 B); to_bricks = false converts back
+long long bricked_bytes(int rx, int ry, int rz);
+hipError_t launch_brick(hipStream_t st, uint8_t* d_lin, int rx, int ry, int rz, uint8_t* d_bricked,
+                        bool to_bricks);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // rm_volgen.hip: the other volume producers of the reference, on the device
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);

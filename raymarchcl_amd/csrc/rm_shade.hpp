@@ -14,6 +14,10 @@
 
 namespace rmk {
 
+#ifndef RM_BRICKS
+#define RM_BRICKS 0  // dist8 / oct8 in 8x4x4-cell bricks (A/B switch; host and device must agree)
+#endif
+
 struct v3 { float x, y, z; };
 RM_DEV v3 V(float x, float y, float z) { return v3{x, y, z}; }
 RM_DEV v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -150,15 +154,29 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
   // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
   // derived structures when ry*rz < 2^24 and rx < 2^24) and an unsigned 32-bit offset
+#if RM_BRICKS
+  // tables are stored in 8x4x4-cell bricks = one 128-byte line each (rm_accel.hip): lanes
+  // of a wavefront and consecutive fetches of a ray then share lines far more often
+  const unsigned nbx = ((unsigned)o.voxelRes[0] + 7u) >> 3, nby = ((unsigned)o.voxelRes[1] + 3u) >> 2;
+  const unsigned brick = __umul24(__umul24((unsigned)qz >> 2, nby) + ((unsigned)qy >> 2), nbx) + ((unsigned)qx >> 3);
+  const unsigned within = ((((unsigned)qz & 3u) << 2 | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
+  const int d = dist8[((brick << 7) | within) + table_off];
+#else
   const unsigned cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
                                  (unsigned)o.voxelRes[0]) + (unsigned)qx;
   const int d = dist8[cell + table_off];
+#endif
   if (dhist) {  // stats build only
     dhist[d < 4 ? d : (d < 8 ? 4 : 5)]++;
     dhist[6] = (unsigned)d;
   }
   if (d == 0) {
+#if RM_BRICKS
+    *cell_out = (int)(__umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
+                               (unsigned)o.voxelRes[0]) + (unsigned)qx);  // surf32 stays row-major
+#else
     *cell_out = (int)cell;
+#endif
     return 1;
   }
   // (the floor argument above needs p >= 0; tiny p also means tiny binades)

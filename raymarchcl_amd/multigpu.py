@@ -133,9 +133,13 @@ class FrameRenderer:
         torch.cuda.synchronize(dev)  # inputs are uploaded before any slot's stream reads them
         root = rank == 0
         self.slots = []
-        for i in range(max(1, int(frames_in_flight))):
-            # slot 0 keeps torch's current stream (what a caller with its own stream expects)
-            stream = torch.cuda.current_stream(dev) if i == 0 else torch.cuda.Stream(dev)
+        nslots = max(1, int(frames_in_flight))
+        for i in range(nslots):
+            # One frame at a time: torch's current stream (what a caller with its own stream
+            # expects).  Several: streams created here back to back -- HIP deals streams to its
+            # few hardware queues round-robin, so these land on distinct queues, whereas the
+            # caller's stream may share one with them (two slots on one queue do not overlap).
+            stream = torch.cuda.current_stream(dev) if nslots == 1 else torch.cuda.Stream(dev)
             slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb)
             slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
             slot.ctx.check_device_opts(self.d_opts.data_ptr(), self.iters, self.n, self.width)

@@ -161,6 +161,7 @@ def test_frames_in_flight(gpu_ctx, config2):
     fr = multigpu.FrameRenderer(sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"], sc["w"],
                                 frames_in_flight=3)
     assert len(fr.slots) == 3 and len({s.stream.cuda_stream for s in fr.slots}) == 3
+    assert torch.cuda.current_stream().cuda_stream not in {s.stream.cuda_stream for s in fr.slots}
     outs = [fr.render() for _ in range(7)]
     torch.cuda.synchronize()
     assert len({o[0].data_ptr() for o in outs}) == 3
