@@ -28,6 +28,10 @@
 __device__ unsigned long long g_work_stats[48];
 #endif
 
+#ifndef RM_WAVE_SHARE
+#define RM_WAVE_SHARE 1  // AO probes and shadow rays of a wavefront's hits dealt to all its lanes
+#endif
+
 namespace {
 
 constexpr int kTile = 8;            // tile edge in pixels; 64 px == one wavefront
@@ -150,7 +154,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32, oct_stride};
   rmk::Tracer<false, ACCEL> tr(sc);
   if (pp > 1) tr.set_pass(mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts_all[pass].time);
+#if RM_WAVE_SHARE
+  static_assert(kWavesPerBlock == 1, "the shared phases use one LDS block per workgroup");
+  __shared__ float wave_lds[rmk::Tracer<false, ACCEL>::kWaveLdsFloats];
+  const rmk::v3 col = ACCEL ? tr.shade_wave(id, wave_lds) : tr.shade(id);
+#else
   const rmk::v3 col = tr.shade(id);
+#endif
   staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
 #ifdef RM_WORK_STATS
   {

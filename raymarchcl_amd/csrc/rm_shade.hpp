@@ -226,6 +226,9 @@ struct Tracer {
   const float4* mc_;
   float time_;
   Counters cnt;  // per-lane, only touched when COUNT
+  // Wave-shared scratch in LDS (kWaveLdsFloats floats of ONE wavefront), or nullptr: lets the
+  // lanes of a wavefront hand AO probes and shadow rays to each other (shade_wave()).
+  float* lds_ = nullptr;
 #ifdef RM_WORK_STATS
   // debug build only: what the accelerated path actually executes
   unsigned int ws_iters = 0, ws_filtered = 0, ws_walks = 0, ws_lookups = 0, ws_jumps = 0, ws_rays = 0,
@@ -900,6 +903,263 @@ struct Tracer {
       col = lighting_math(s, rdir, hpos, m, norm, refl, r0.x, __float_as_uint(r0.y));
     }
     return atmosphere(s, s.eye, rdir, hdist, col) * o.exposure;
+  }
+
+
+  // =====================================================================================
+  // The same sample with its secondary rays SHARED by the wavefront.
+  //
+  // In sample_colour() the AO probes and shadow marches of a hit run in the lane that owns the
+  // hit while lanes without one (sky, or done earlier) idle: 25 % / 37 % of the lane slots of
+  // those walks do work.  Every such ray is a pure function of a few floats of its owner
+  // (position, normal, seed / light jitter), so ANY lane can trace it: the owners post their
+  // inputs in LDS, the (owner, probe) and (owner, light) tasks are dealt round-robin to all
+  // lanes of the wavefront, results come back through LDS and the owners combine them in the
+  // reference's order.  Per task the operations are the ones of occlusion() / lighting(), so
+  // the bits do not change.  Control flow around the shared phases is wave-uniform (decided by
+  // ballots), which is what lets idle lanes take part.
+  // =====================================================================================
+  static constexpr int kWaveLdsIn = 9;    // posted inputs per lane
+  static constexpr int kWaveLdsRes = 8;   // results per lane (AO probes <= 8, lights <= 4)
+  static constexpr int kWaveLdsFloats = (kWaveLdsIn + kWaveLdsRes + 1) * 64;
+  RM_DEV float& lds_in(int f, int lane) { return lds_[f * 64 + lane]; }
+  RM_DEV float& lds_res(int f, int lane) { return lds_[(kWaveLdsIn + f) * 64 + lane]; }
+  RM_DEV int& lds_map(int rank) { return reinterpret_cast<int*>(lds_)[(kWaveLdsIn + kWaveLdsRes) * 64 + rank]; }
+  RM_DEV static void wave_sync() { __syncthreads(); }  // one wavefront per workgroup: orders its LDS traffic
+
+  struct Deal {  // who does what in a shared phase
+    int lane, helpers, my_slot, owners, my_rank;
+  };
+  RM_DEV Deal deal(bool active) {
+    Deal dl;
+    const unsigned long long here = __ballot(1), own = __ballot(active);
+    dl.lane = (int)(threadIdx.x & 63);
+    const unsigned long long below = (1ull << dl.lane) - 1ull;
+    dl.helpers = __popcll(here);
+    dl.my_slot = __popcll(here & below);
+    dl.owners = __popcll(own);
+    dl.my_rank = __popcll(own & below);
+    return dl;
+  }
+  // t / a and t % a for 0 <= t < 1024, 1 <= a <= 64 without an integer division
+  RM_DEV static void divmod_small(int t, int a, int& q, int& r) {
+    q = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)a));
+    r = t - q * a;
+    if (r < 0) { q--; r += a; }
+    if (r >= a) { q++; r -= a; }
+  }
+
+  // occlusion() for all lanes of the wavefront at once; `active` lanes own a hit
+  RM_DEV float occlusion_wave(bool active, const Sample& s, v3 pos, v3 normal) {
+    const RmOpts& o = *sc.o;
+    const int np = o.aoIter + 1;
+    const Deal dl = deal(active);
+    if (dl.owners == 0) return 1.0f;
+    if (np > kWaveLdsRes) return active ? occlusion(s, pos, normal) : 1.0f;  // (uniform) too many probes to post
+    const uint32_t seed0 =
+        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+    if (active) {
+      RM_WS(ws_probes++);
+      lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
+      lds_in(3, dl.lane) = normal.x; lds_in(4, dl.lane) = normal.y; lds_in(5, dl.lane) = normal.z;
+      lds_in(6, dl.lane) = __uint_as_float(seed0);
+      const unsigned long long tp = (unsigned long long)mc_;
+      lds_in(7, dl.lane) = __uint_as_float((uint32_t)tp);
+      lds_in(8, dl.lane) = __uint_as_float((uint32_t)(tp >> 32));
+      lds_map(dl.my_rank) = dl.lane;
+    }
+    wave_sync();
+    const int tasks = np * dl.owners;
+#ifdef RM_WORK_STATS
+    const int ws_kind_saved = ws_kind;
+    ws_kind = 3;
+#endif
+    for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
+      const int t = base + dl.my_slot;
+      if (t < tasks) {
+        int probe, rank;
+        divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
+        const int owner = lds_map(rank);
+        const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
+        const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
+        const uint32_t seed = __float_as_uint(lds_in(6, owner)) + 37u * (uint32_t)(probe + 1);
+        const float4* tab = reinterpret_cast<const float4*>(
+            (unsigned long long)__float_as_uint(lds_in(7, owner)) |
+            ((unsigned long long)__float_as_uint(lds_in(8, owner)) << 32));
+        float d = 0.0f, dj = 0.0f;  // d of probe i = i+1 sequential adds (renderer.cl:339)
+        for (int j = 0; j < np; j++) {
+          dj += o.aoStepDist;
+          if (j == probe) d = dj;
+        }
+        const float4 r = tab[seed & (RM_TABLE_ENTRIES - 1)];
+        const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, onrm));
+        float sd, scode;
+        v3 nn;
+        scene_distance(mads(n, d, opos), n, o.maxVoxelIter / 2, false, sd, scode, nn);
+        lds_res(probe, owner) = sd;
+      }
+    }
+    RM_WS(ws_kind = ws_kind_saved);
+    wave_sync();
+    float ao = 1.0f;
+    if (active) {
+      float d = 0.0f;
+      for (int i = 0; i < np && (double)ao > 0.01; i++) {  // renderer.cl:338-344
+        d += o.aoStepDist;
+        ao *= 1.0f - rmd::fmax_cl((d - lds_res(i, dl.lane)) * o.aoAmp / d, 0.0f);
+      }
+    }
+    wave_sync();  // the posted values are dead: the next shared phase may overwrite them
+    return ao;
+  }
+
+  // the shadow marches of lighting() for all lanes: distance reached by the march towards
+  // light i in lds_res(i, lane) (only where the light passes the attenuation test)
+  RM_DEV void shadows_wave(bool active, v3 hitpos, v3 jit) {
+    const RmOpts& o = *sc.o;
+    const int nl = o.numLights;
+    const Deal dl = deal(active);
+    if (dl.owners == 0 || nl <= 0) return;
+    if (active) {
+      lds_in(0, dl.lane) = hitpos.x; lds_in(1, dl.lane) = hitpos.y; lds_in(2, dl.lane) = hitpos.z;
+      lds_in(3, dl.lane) = jit.x; lds_in(4, dl.lane) = jit.y; lds_in(5, dl.lane) = jit.z;
+      lds_map(dl.my_rank) = dl.lane;
+    }
+    wave_sync();
+    const int tasks = nl * dl.owners;
+#ifdef RM_WORK_STATS
+    const int ws_kind_saved = ws_kind;
+    ws_kind = 2;
+#endif
+    for (int base = 0; base < tasks; base += dl.helpers) {
+      const int t = base + dl.my_slot;
+      if (t < tasks) {
+        int light, rank;
+        divmod_small(t, dl.owners, light, rank);
+        const int owner = lds_map(rank);
+        const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
+        const v3 ojit = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
+        // the expressions of lighting() (renderer.cl:356-362)
+        const v3 dlv = mads(ojit, o.lightScatter, ld3(o.lightPos[light])) - opos;
+        const float d2 = dot(dlv, dlv);
+        const float att = 1.0f / d2;
+        if (att > o.minLightAtt) {
+          const v3 ldir = normalize(dlv);
+          const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
+          Hit h{};
+          march(mads(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false);
+          lds_res(light, owner) = h.distance;
+        }
+      }
+    }
+    RM_WS(ws_kind = ws_kind_saved);
+    wave_sync();
+  }
+
+  // lighting() with the rays of all hits of the wavefront traced together
+  RM_DEV v3 lighting_wave(bool active, const Sample& s, v3 raydir, v3 hitpos, const Material& m,
+                          v3 normal, v3 reflectCol) {
+    const RmOpts& o = *sc.o;
+    if (__ballot(active) == 0) return V(0.f, 0.f, 0.f);  // uniform
+    const float ao = occlusion_wave(active, s, hitpos, normal);
+    // light jitter: one table value for all lights (renderer.cl:263-269)
+    v3 jit = V(0.f, 0.f, 0.f);
+    if (active) {
+      const float4 r = table(rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
+      jit = V(r.x, r.y, r.z);
+    }
+    shadows_wave(active, hitpos, jit);
+    v3 res = V(0.f, 0.f, 0.f);
+    if (active) {
+      v3 diff = sky(normal) * ao;
+      v3 spec = reflectCol * ao;
+      v3 out = V(0.f, 0.f, 0.f);
+      const int nl = o.numLights;
+      const int lane = (int)(threadIdx.x & 63);
+      for (int i = 0; i < nl; i++) {
+        const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
+        const float d2 = dot(dl, dl);
+        const float att = 1.0f / d2;
+        if (att > o.minLightAtt) {
+          const v3 ldir = normalize(dl);
+          const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
+          const float sh = rmd::step_cl(lmax, lds_res(i, lane));
+          if (sh > 0.0f) {
+            const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
+            diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+            spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+          }
+        }
+        diff = diff * m.albedo;
+        out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
+      }
+      const float fl = (float)nl;
+      res = V(out.x / fl, out.y / fl, out.z / fl);
+    }
+    wave_sync();  // results consumed before the next shared phase posts
+    return res;
+  }
+
+  // sample_colour() with wave-uniform control flow around the shared phases
+  RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir) {
+    const RmOpts& o = *sc.o;
+    Hit h{};
+    march(ro, rdir, h, o.maxDist, o.maxIter, true);
+    const bool hit = !(h.distance >= o.maxDist);
+    Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
+    v3 norm = V(0.f, 0.f, 0.f);
+    if (hit) {
+      m = material(h.objectID);
+      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      norm = mads(s.mcNormal, k, h.normal);
+    }
+    const bool bounces = hit && m.r0 > 0.0f && o.reflectIter > 0;
+    v3 refl = V(0.f, 0.f, 0.f);
+    if (__ballot(bounces) != 0) {  // uniform
+      Hit rh{};
+      rh.pos = h.pos;
+      rh.normal = norm;
+      v3 dir = rdir;
+      bool alive = bounces;
+      for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
+        if (__ballot(alive) == 0) break;         // uniform
+        v3 from = V(0.f, 0.f, 0.f);
+        if (alive) {
+          dir = reflect(dir, rh.normal);
+          from = mads(dir, 0.0075f, rh.pos);
+          RM_WS(ws_kind = 1);
+          march(from, dir, rh, o.maxDist, o.maxIter, false);  // bounce_colour(), renderer.cl:383-405
+          RM_WS(ws_kind = 0);
+        }
+        const bool bhit = alive && rh.objectID >= 0;
+        Material bm{V(0.f, 0.f, 0.f), 0.f, 0.f};
+        v3 brefl = V(0.f, 0.f, 0.f);
+        if (bhit) {
+          bm = material(rh.objectID);
+          brefl = sky(reflect(dir, rh.normal));
+        }
+        const v3 lit = lighting_wave(bhit, s, dir, rh.pos, bm, rh.normal, brefl);
+        if (alive) {
+          const v3 col = bhit ? lit : sky(dir);
+          refl = refl + atmosphere(s, from, dir, rh.distance, col);
+          if (rh.objectID < 0) alive = false;
+          else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
+        }
+      }
+    }
+    if (hit && !bounces) refl = sky(reflect(rdir, norm));
+    const v3 lit = lighting_wave(hit, s, rdir, h.pos, m, norm, refl);
+    const v3 col = hit ? lit : sky(rdir);
+    return atmosphere(s, ro, rdir, h.distance, col);
+  }
+
+  // shade() through the wave-shared path; every lane of the wavefront that has a pixel
+  // must call it (lanes without one have left the kernel), lds = kWaveLdsFloats floats
+  RM_DEV v3 shade_wave(int id, float* lds) {
+    lds_ = lds;
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    return sample_colour_wave(s, s.eye, rdir) * sc.o->exposure;
   }
 
   // colour * exposure of work-item `id` (the value RenderImage blends in, renderer.cl:491)
