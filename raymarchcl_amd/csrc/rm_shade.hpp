@@ -206,15 +206,16 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   return 0;
 }
 
-// Two exact instruction-count reductions that measured SLOWER on the 64-VGPR build
-// (10.95 ms without, 10.98 / 11.10 / 11.16 ms with the first / second / both): the kernel
-// is bound by exposed fetch latency and register pressure, not by VALU issue.  Kept
-// switchable for re-measuring after changes to the register budget (tools/ab_build.py).
+// Two exact instruction-count reductions of the per-estimate set-up.  On the build
+// before the wave-shared AO/shadow phases they measured slower (10.95 ms without, 10.98 /
+// 11.10 / 11.16 ms with the first / second / both: register pressure); with the shared
+// phases 8.87 ms without, 8.78 / 8.89 / 8.73 ms.  Switchable for re-measuring
+// (tools/ab_build.py).
 #ifndef RM_FASTDIV
-#define RM_FASTDIV 0      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
+#define RM_FASTDIV 1      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
 #endif
 #ifndef RM_INSIDE_TEST
-#define RM_INSIDE_TEST 0  // AO probes: skip the slab test when the position is inside the box
+#define RM_INSIDE_TEST 1  // skip the slab test when the position is inside the box by a margin
 #endif
 template <bool COUNT, bool ACCEL = false>
 struct Tracer {
