@@ -421,49 +421,67 @@ struct Tracer {
   // ambiguous estimates (and those that do walk) run the exact code.  The
   // outcome of every skipped test is certain, so results do not change.
   struct BoxFilter {
-    float near0, far0, slack;
-    bool ok;
+    // thresholds on the march distance t (>= 0) derived once per ray from the approximate
+    // entry / exit parameters near0 / far0 and their error bound `slack`; each comparison
+    // below implies the corresponding statement about the exact slab test with the margin
+    // m(t) = slack + 8e-6 |t| (t-proportional rounding of the reference's own evaluation)
+    float past;    // t > past            =>  far0 - t < -m(t): the box is entirely behind
+    float before;  // t + 8e-6|t| + g < before  =>  near0 - t > g + m(t): entry farther than the ground term
+                   //   (a line that misses the box by a margin gets before = 64: true while t <= 64)
+    float in_lo, in_hi;  // in_lo <= t < in_hi  =>  near0 - t < -m(t) and far0 - t > m(t): inside the box
+    float slack;
   };
   RM_DEV BoxFilter make_filter(v3 ro, v3 rd) {
     const RmOpts& o = *sc.o;
     BoxFilter f;
     const float ax = __builtin_fabsf(rd.x), ay = __builtin_fabsf(rd.y), az = __builtin_fabsf(rd.z);
     // tiny components make the parameters huge (and 0 makes them inf/NaN): no filter
-    f.ok = fminf(fminf(ax, ay), az) >= 1e-3f && fmaxf(fmaxf(ax, ay), az) <= 2.0f &&
-           fmaxf(fmaxf(__builtin_fabsf(ro.x), __builtin_fabsf(ro.y)), __builtin_fabsf(ro.z)) <= 64.0f;
+    const bool ok = fminf(fminf(ax, ay), az) >= 1e-3f && fmaxf(fmaxf(ax, ay), az) <= 2.0f &&
+                    fmaxf(fmaxf(__builtin_fabsf(ro.x), __builtin_fabsf(ro.y)), __builtin_fabsf(ro.z)) <= 64.0f &&
+                    o.startDist >= 0.0f && o.startDist <= 64.0f;
     const float ix = __builtin_amdgcn_rcpf(rd.x), iy = __builtin_amdgcn_rcpf(rd.y),
                 iz = __builtin_amdgcn_rcpf(rd.z);
     const float lx = (o.voxelBoundsMin[0] - ro.x) * ix, hx = (o.voxelBoundsMax[0] - ro.x) * ix;
     const float ly = (o.voxelBoundsMin[1] - ro.y) * iy, hy = (o.voxelBoundsMax[1] - ro.y) * iy;
     const float lz = (o.voxelBoundsMin[2] - ro.z) * iz, hz = (o.voxelBoundsMax[2] - ro.z) * iz;
-    f.near0 = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz));
-    f.far0 = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz));
+    const float near0 = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz));
+    const float far0 = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz));
     // positions are rounded to ~4e-6 and divided by >= 1e-3, quotients (< 7e4) to ~8e-3
-    f.slack = 0.03f + 8e-6f * (__builtin_fabsf(f.near0) + __builtin_fabsf(f.far0));
+    const float slack = 0.03f + 8e-6f * (__builtin_fabsf(near0) + __builtin_fabsf(far0));
+    f.slack = slack;
+    // t(1 - 8e-6) > far0 + slack, with t >= 0
+    f.past = fmaxf(far0 + slack, 0.0f) * 1.00002f;
+    // the line misses the box (b < a) by more than m(64): no walk anywhere up to t = 64
+    const bool miss = far0 - near0 < -(slack + 6e-4f);
+    f.before = miss ? 64.0f : near0 - slack * 1.01f;
+    f.in_lo = fmaxf(near0 + slack, 0.0f) * 1.00002f;
+    f.in_hi = (far0 - slack) * 0.99998f;  // (<= 0: never inside)
+    if (!ok) {
+      f.past = __builtin_inff();
+      f.before = -__builtin_inff();
+      f.in_hi = -1.0f;
+    }
     return f;
   }
   // true when the estimate at distance t certainly returns the ground/sky term
   // (renderer.cl:214 condition false) -- ground distance `g` = res.x there
   RM_DEV bool surely_no_walk(const BoxFilter& f, float t, float g) {
     // (straight-line on purpose: this sits in the hottest loop of the march)
-    const float m = __builtin_fmaf(__builtin_fabsf(t), 8e-6f, f.slack);
-    return f.ok & ((g <= 0.0f)                              // entry distance is >= 0 or -1: never < g
-                   | (fminf(f.far0 - t, f.far0 - f.near0) < -m)  // box entirely behind (b < 0 <= a) or missed (b < a)
-                   | (f.near0 - t > g + m));                // entry farther than the ground term
+    return (g <= 0.0f)                                               // entry distance is >= 0 or -1: never < g
+           | (t > f.past)                                            // box entirely behind
+           | (__builtin_fmaf(__builtin_fabsf(t), 8e-6f, t) + g < f.before);  // entry farther than the ground term / box missed
   }
   // true when the position at distance t is certainly inside the clip box and the ground
   // term is positive by a margin: the reference's slab test returns exactly +0 < g
   RM_DEV bool surely_inside(const BoxFilter& f, float t, float g) {
-    const float m = f.slack + 8e-6f * __builtin_fabsf(t);
-    return f.ok & (f.near0 - t < -m) & (f.far0 - t > m) & (g > m);
+    return (t >= f.in_lo) & (t < f.in_hi) & (g > __builtin_fmaf(__builtin_fabsf(t), 8e-6f, f.slack));
   }
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
     RM_WS(ws_rays++);
     float dist = o.startDist;
-    BoxFilter flt;
-    flt.ok = false;
+    BoxFilter flt{};
     if (!COUNT) flt = make_filter(ro, rdir);
     // Only the LAST estimate's position, code and normal survive the loop
     // (renderer.cl:244-246 overwrite them every turn), so the filtered turns -- the
