@@ -232,3 +232,41 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
             px, argb = ctx.render_frame(opts, sc["mc"], n)
         assert _eq(px, want), (env, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
         assert np.array_equal(argb, want_argb), env
+
+
+@pytest.mark.parametrize("name,over", [
+    ("ao8", dict(aoIter=7)),                      # 8 probes: the most the shared AO phase posts
+    ("ao10_fallback", dict(aoIter=9)),            # more: every owner runs its own probes
+    ("ao1", dict(aoIter=0)),
+    ("one_light", dict(numLights=1)),
+    ("four_lights", dict(numLights=4, lightPos=[[-2, 0, -2, 0], [2, 0, 2, 0], [0, 3, 0, 0], [-3, 1, 2, 0]],
+                         lightColor=[[28, 18, 8, 0], [8, 18, 28, 0], [10, 10, 10, 0], [5, 20, 5, 0]])),
+    ("attenuation_cut", dict(minLightAtt=0.12)),  # some (point, light) pairs skip their shadow ray
+    ("three_bounces", dict(reflectIter=3)),
+    ("no_lights", dict(numLights=0)),
+])
+def test_shared_secondary_rays_against_oracle(oracle_mod, native, name, over):
+    """The wave-shared AO / shadow phases (rm_shade.hpp shade_wave) with other probe and light
+    counts than the presets use: whole frames (2 passes, pass-packed) == oracle, bit for bit."""
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen
+    from raymarchcl_amd import structs
+
+    w, h, it, vres = 48, 40, 2, 64
+    vox = scenes.volume("gyroid", vres)
+    recs = []
+    for i in range(it):
+        o = rm.render_options(width=w, height=h, vres=[vres] * 3, t=i * 0.333, iter=it,
+                              eyepos=rm.compute_eyepos(150, 2.1, 0.4), targetpos=[0, -0.3, 0], mat="metal")
+        o.update(over)
+        recs.append(structs.encode_bytes(o))
+    opts = b"".join(recs)
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=77 + i) for i in range(it)])
+    n = w * h
+    want, want_argb = oracle_mod.render_frame(vox, opts, mc, n)
+    with native.Context(0) as ctx:
+        ctx.set_volume(vox, (vres,) * 3)
+        px, argb = ctx.render_frame(opts, mc, n)
+    assert _eq(px, want), (name, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
+    assert np.array_equal(argb, want_argb)
+    assert len(np.unique(argb)) > 20
