@@ -16,7 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 # variant built with extra flags by tools/ab_build.py; the product default is the name below
 LIB_PATH = os.path.join(HERE, os.path.basename(os.environ.get("RAYMARCH_LIB", "libraymarch_hip.so")))
 SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_volgen.hip", "rm_stream.hip", "rm_api.hip", "rm_host.cpp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize: packed f32 VALU (v_pk_add_f32 ...) buys nothing on this chip and its
+# even-aligned register pairs cost moves and spills in a 64-VGPR kernel (measured -5 % frame time)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-shared"]
 
 OPTS_BYTES = 544
 TABLE_FLOATS = 0x4000 * 4
@@ -64,6 +67,7 @@ def _stale():
     t = os.path.getmtime(LIB_PATH)
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     files.append(os.path.join(HERE, "..", "include", "raymarch_hip.h"))
+    files.append(os.path.abspath(__file__))  # the compiler flags live here
     return any(os.path.getmtime(f) > t for f in files if os.path.isfile(f))
 
 
