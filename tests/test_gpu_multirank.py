@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, frames_in_flight=1):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -38,8 +38,9 @@ def _worker(rank, world, port, tmpdir):
     torch.cuda.set_device(0)
     sc = scenes.build("metal_3spp")
     fr = multigpu.FrameRenderer(sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"], sc["w"], rank=rank,
-                                world=world, device=torch.device("cuda", 0))
-    for _ in range(2):  # twice: the second frame reuses every buffer
+                                world=world, device=torch.device("cuda", 0),
+                                frames_in_flight=frames_in_flight)
+    for _ in range(2 * frames_in_flight + 1):  # every slot reused at least once
         d_px, d_argb = fr.render()
     torch.cuda.synchronize()
     if rank == 0:
@@ -50,11 +51,11 @@ def _worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_tile_partition_over_ranks(tmp_path, oracle_mod, world):
+@pytest.mark.parametrize("world,frames_in_flight", [(2, 1), (3, 1), (2, 2)])
+def test_tile_partition_over_ranks(tmp_path, oracle_mod, world, frames_in_flight):
     import scenes
 
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), frames_in_flight), nprocs=world, join=True)
     sc = scenes.build("metal_3spp")
     want, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
     px = np.load(tmp_path / "px.npy")
