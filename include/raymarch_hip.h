@@ -125,6 +125,23 @@ int rm_tonemap_image(rm_ctx* ctx, const float* pixels, const void* opts544, uint
 int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, int iter, int n,
                     float* pixels_out, uint32_t* argb_out);
 
+/* ---- QUALITY MODE: not a reference feature, not reference-equivalent ----
+ * What the north star's prose describes and the reference does not implement: the
+ * distance estimate comes from a float distance field sampled TRILINEARLY (cell centres,
+ * world units, negative inside), the hit normal is its gradient (central differences,
+ * step voxelSize), light visibility is a soft penumbra term min(k*clearance/distance),
+ * k = 1/lightScatter.  Everything else -- the march (= sphere tracing with the estimate as
+ * the step), AO, lighting, reflections, atmosphere, pass blending, tonemap, and the
+ * 544-byte option record -- is the reference path.  Checked bit for bit against a CPU
+ * restatement of the same algorithm (oracle/rm_restate.c sdf_*), which is its only pin.
+ *
+ * rm_set_sdf_volume: rx*ry*rz float32, x fastest, copied to HBM (independent of the byte
+ * volume).  rm_render_sdf_frame: as rm_render_frame; voxelRes of the records must equal
+ * the field's size; isoVal is ignored. */
+int rm_set_sdf_volume(rm_ctx* ctx, const float* sdf, int rx, int ry, int rz);
+int rm_render_sdf_frame(rm_ctx* ctx, const void* opts544_array, const float* mc_array, int iter,
+                        int n, float* pixels_out, uint32_t* argb_out);
+
 /* ---- device-resident form of the same pipeline (inputs already in HBM) ----
  * The image is cut into 8x8-pixel tiles, numbered row-major; partition
  * (tile_first, tile_stride) owns tiles tile_first, tile_first+tile_stride, ...

@@ -82,6 +82,9 @@ def restate_lib():
         lib.rmo_render_frame.argtypes = [_u8p, ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, _u32p,
                                          ctypes.c_int, ctypes.c_int, ctypes.POINTER(Stats)]
         lib.rmo_render_frame.restype = None
+        lib.rmo_render_sdf_frame.argtypes = [_f32p, ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, _u32p,
+                                             ctypes.c_int, ctypes.c_int]
+        lib.rmo_render_sdf_frame.restype = None
         lib.rmo_hw_threads.restype = ctypes.c_int
         for name in ("rmo_exp", "rmo_exp2"):
             getattr(lib, name).argtypes = [ctypes.c_float]
@@ -150,6 +153,21 @@ def tonemap_image(pixels, opts, n=None):
     ob = ctypes.create_string_buffer(bytes(opts)[:OPTS_SIZE], OPTS_SIZE)
     restate_lib().rmo_tonemap_image(_ptr(pixels, _f32p), ob, _ptr(argb, _u32p), n, 0, n)
     return argb
+
+
+def render_sdf_frame(sdf, opts_array, mc_array, n, threads=0):
+    """QUALITY MODE (not the reference's algorithm): the pipeline over a float32 distance
+    field [rz, ry, rx].  -> (pixels float32[n*4], argb uint32[n])"""
+    iters = len(opts_array) // OPTS_SIZE
+    sdf = np.ascontiguousarray(sdf, dtype=np.float32).reshape(-1)
+    mc_array = np.ascontiguousarray(mc_array, dtype=np.float32).reshape(-1)
+    assert mc_array.size == iters * TABLE_FLOATS
+    pixels = np.zeros(n * 4, dtype=np.float32)
+    argb = np.zeros(n, dtype=np.uint32)
+    ob = ctypes.create_string_buffer(bytes(opts_array), len(opts_array))
+    restate_lib().rmo_render_sdf_frame(_ptr(sdf, _f32p), ob, _ptr(mc_array, _f32p), iters,
+                                       _ptr(pixels, _f32p), _ptr(argb, _u32p), n, threads)
+    return pixels, argb
 
 
 def render_frame(vox, opts_array, mc_array, n, threads=0, stats=None, tonemap=True):

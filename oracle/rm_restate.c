@@ -62,6 +62,7 @@ typedef struct {
 typedef struct {
   const uint8_t* vox;
   const float* mc;
+  const float* sdf; /* quality mode (NOT the reference's algorithm): float distance field, or NULL */
   uint8_t raw[OPTS_SIZE];
   /* decoded copies of the hot fields */
   v3 eyePos, targetPos, up, vb, vb2, vbMin, vbMax, ivs, sky1, sky2;
@@ -78,6 +79,7 @@ static int ldi(const uint8_t* raw, int off) { int32_t i; memcpy(&i, raw + off, 4
 static v3 ld3(const uint8_t* raw, int off) { v3 v = {ldf(raw, off), ldf(raw, off + 4), ldf(raw, off + 8)}; return v; }
 
 static void ctx_init(ctx_t* c, const uint8_t* vox, const float* mc, const void* opts544) {
+  c->sdf = NULL;
   memset(c, 0, sizeof *c);
   c->vox = vox; c->mc = mc;
   memcpy(c->raw, opts544, OPTS_SIZE);
@@ -207,9 +209,92 @@ static float band(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }
 
 /* ---- distance estimate at rpos along dir: renderer.cl:209-237 ----
  * returns distance in *dist, material code in *code, surface normal in *nrm */
+/* ======================================================================================
+ * QUALITY MODE -- not a reference feature and not reference-equivalent:
+ * the estimate comes from a float distance field sampled trilinearly, the hit normal is
+ * its gradient, shadows are soft.  Everything around it (march = sphere tracing with the
+ * estimate as the step, AO, lighting, reflections, atmosphere, blend, tonemap) is the code
+ * above.  Same arithmetic contract, so the HIP kernel can be checked bit for bit.
+ * ====================================================================================== */
+/* field value at a position inside (or on) the clip box: trilinear over cell centres */
+static float sdf_sample(const ctx_t* c, v3 q) {
+  const float ux = cl_clamp((q.x + c->vb.x) * c->ivs.x * (float)c->rx - 0.5f, 0.0f, (float)(c->rx - 1));
+  const float uy = cl_clamp((q.y + c->vb.y) * c->ivs.y * (float)c->ry - 0.5f, 0.0f, (float)(c->ry - 1));
+  const float uz = cl_clamp((q.z + c->vb.z) * c->ivs.z * (float)c->rz - 0.5f, 0.0f, (float)(c->rz - 1));
+  int ix = (int)ux, iy = (int)uy, iz = (int)uz; /* u >= 0: truncation = floor */
+  if (ix > c->rx - 2) ix = c->rx - 2;
+  if (iy > c->ry - 2) iy = c->ry - 2;
+  if (iz > c->rz - 2) iz = c->rz - 2;
+  if (ix < 0) ix = 0;
+  if (iy < 0) iy = 0;
+  if (iz < 0) iz = 0;
+  const float fx = ux - (float)ix, fy = uy - (float)iy, fz = uz - (float)iz;
+  const int x1 = ix + 1 < c->rx ? ix + 1 : ix, y1 = iy + 1 < c->ry ? iy + 1 : iy,
+            z1 = iz + 1 < c->rz ? iz + 1 : iz;
+  const float* g = c->sdf;
+#define SDF_AT(X, Y, Z) g[((size_t)(Z) * c->ry + (Y)) * c->rx + (X)]
+  const float a00 = SDF_AT(ix, iy, iz) + (SDF_AT(x1, iy, iz) - SDF_AT(ix, iy, iz)) * fx;
+  const float a10 = SDF_AT(ix, y1, iz) + (SDF_AT(x1, y1, iz) - SDF_AT(ix, y1, iz)) * fx;
+  const float a01 = SDF_AT(ix, iy, z1) + (SDF_AT(x1, iy, z1) - SDF_AT(ix, iy, z1)) * fx;
+  const float a11 = SDF_AT(ix, y1, z1) + (SDF_AT(x1, y1, z1) - SDF_AT(ix, y1, z1)) * fx;
+#undef SDF_AT
+  const float b0 = a00 + (a10 - a00) * fy;
+  const float b1 = a01 + (a11 - a01) * fy;
+  return b0 + (b1 - b0) * fz;
+}
+/* distance to the field's zero set from anywhere: outside the clip box the distance to the
+ * box is added to the value at the nearest point of the box */
+static float sdf_volume(const ctx_t* c, v3 p) {
+  const v3 q = V(cl_clamp(p.x, c->vbMin.x, c->vbMax.x), cl_clamp(p.y, c->vbMin.y, c->vbMax.y),
+                 cl_clamp(p.z, c->vbMin.z, c->vbMax.z));
+  return sdf_sample(c, q) + length3(sub(p, q));
+}
+static void scene_distance_sdf(ctx_t* c, v3 rpos, v3 dir, float* dist, float* code, v3* nrm) {
+  const float h = rpos.y + c->groundY;
+  float rd, rc;
+  if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
+  *nrm = ((double)rd < 1e5) ? V(0.0f, 1.0f, 0.0f) : neg(dir);
+  const float dv = sdf_volume(c, rpos);
+  if (dv < rd) {
+    rd = dv;
+    rc = 1.0f;
+    if (dv <= c->eps * 2.0f) { /* close enough to be the hit: gradient by central differences */
+      const float e = c->voxelSize;
+      const v3 g = V(sdf_volume(c, V(rpos.x + e, rpos.y, rpos.z)) - sdf_volume(c, V(rpos.x - e, rpos.y, rpos.z)),
+                     sdf_volume(c, V(rpos.x, rpos.y + e, rpos.z)) - sdf_volume(c, V(rpos.x, rpos.y - e, rpos.z)),
+                     sdf_volume(c, V(rpos.x, rpos.y, rpos.z + e)) - sdf_volume(c, V(rpos.x, rpos.y, rpos.z - e)));
+      *nrm = normalize3(g);
+    } else {
+      *nrm = neg(dir);
+    }
+  }
+  *dist = rd;
+  *code = rc;
+}
+/* penumbra estimate along a light ray: min over the march of k * clearance / distance */
+static float scene_only_distance_sdf(ctx_t* c, v3 p) {
+  const float h = p.y + c->groundY;
+  const float g = h < 1e5f ? h : 1e5f;
+  return cl_min(g, sdf_volume(c, p));
+}
+static float soft_shadow_sdf(ctx_t* c, v3 p, v3 ldir, float lmax) {
+  const float k = 1.0f / cl_max(c->lightScatter, 0.01f);
+  float res = 1.0f;
+  float t = 0.0f;
+  for (int i = 0; i < c->shadowIter; i++) {
+    const float d = scene_only_distance_sdf(c, mad3s(ldir, t, p));
+    if (d <= c->eps * 0.5f) return 0.0f;
+    res = cl_min(res, k * d / (t + c->shadowBias));
+    t += cl_max(d, c->eps);
+    if (t >= lmax) break;
+  }
+  return cl_clamp(res, 0.0f, 1.0f);
+}
+
 static void scene_distance(ctx_t* c, v3 rpos, v3 dir, int steps, int smooth, float* dist,
                            float* code, v3* nrm) {
   c->st.dts_calls++;
+  if (c->sdf) { scene_distance_sdf(c, rpos, dir, dist, code, nrm); return; }
   const float h = rpos.y + c->groundY;
   float rd, rc;
   if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
@@ -350,8 +435,9 @@ static v3 lighting(ctx_t* c, const sample_t* s, v3 raydir, v3 hitpos, const mat_
     const float att = 1.0f / d2;
     if (att > c->minLightAtt) {
       const v3 ldir = normalize3(dl);
-      const float sh = shadow_term(c, mad3s(ldir, c->shadowBias, hitpos), ldir,
-                                   cl_min(cl_sqrt(d2) - c->shadowBias, c->maxDist));
+      const float lmax = cl_min(cl_sqrt(d2) - c->shadowBias, c->maxDist);
+      const float sh = c->sdf ? soft_shadow_sdf(c, mad3s(ldir, c->shadowBias, hitpos), ldir, lmax)
+                              : shadow_term(c, mad3s(ldir, c->shadowBias, hitpos), ldir, lmax);
       if (sh > 0.0f) {
         const v3 inc = muls(muls(light_color_opt(c, i), sh), att);
         diff = add(diff, muls(inc, diffuse_term(ldir, normal)));
@@ -468,7 +554,7 @@ int rmo_hw_threads(void) {
  * threads <= 0: all hardware threads.  stats (nullable) is ADDED to. */
 static void render_image_impl(const uint8_t* vox, const float* mc, const void* opts544,
                               float* pixels, int n, int id0, int id1, int threads,
-                              rmo_stats* stats, uint8_t* undefined_mask) {
+                              rmo_stats* stats, uint8_t* undefined_mask, const float* sdf) {
   if (id1 > n) id1 = n;
   if (id0 < 0) id0 = 0;
 #ifdef _OPENMP
@@ -482,6 +568,7 @@ static void render_image_impl(const uint8_t* vox, const float* mc, const void* o
   {
     ctx_t c;
     ctx_init(&c, vox, mc, opts544);
+    c.sdf = sdf;
 #pragma omp for schedule(dynamic, 64)
     for (int id = id0; id < id1; id++) {
       const uint64_t before = c.st.oob_material;
@@ -496,7 +583,7 @@ static void render_image_impl(const uint8_t* vox, const float* mc, const void* o
 
 void rmo_render_image(const uint8_t* vox, const float* mc, const void* opts544, float* pixels,
                       int n, int id0, int id1, int threads, rmo_stats* stats) {
-  render_image_impl(vox, mc, opts544, pixels, n, id0, id1, threads, stats, NULL);
+  render_image_impl(vox, mc, opts544, pixels, n, id0, id1, threads, stats, NULL, NULL);
 }
 /* Same; additionally sets undefined_mask[id] = 1 for every work-item that
  * indexed materials[] outside the option record -- behaviour the reference
@@ -505,7 +592,7 @@ void rmo_render_image(const uint8_t* vox, const float* mc, const void* opts544, 
 void rmo_render_image_masked(const uint8_t* vox, const float* mc, const void* opts544,
                              float* pixels, int n, int id0, int id1, int threads,
                              rmo_stats* stats, uint8_t* undefined_mask) {
-  render_image_impl(vox, mc, opts544, pixels, n, id0, id1, threads, stats, undefined_mask);
+  render_image_impl(vox, mc, opts544, pixels, n, id0, id1, threads, stats, undefined_mask, NULL);
 }
 
 /* TonemapImage: renderer.cl:448-454, 496-508 */
@@ -535,6 +622,18 @@ void rmo_render_frame(const uint8_t* vox, const void* opts_array, const float* m
     rmo_render_image(vox, mc_array + (size_t)i * 0x4000 * 4,
                      (const uint8_t*)opts_array + (size_t)i * OPTS_SIZE, pixels, n, 0, n, threads,
                      stats);
+  if (argb) rmo_tonemap_image(pixels, opts_array, argb, n, 0, n);
+}
+
+/* QUALITY MODE frame: the pipeline above over a float distance field (rx*ry*rz floats, x
+ * fastest, voxelRes of the records) instead of the byte grid.  Not reference-equivalent. */
+void rmo_render_sdf_frame(const float* sdf, const void* opts_array, const float* mc_array, int iter,
+                          float* pixels, uint32_t* argb, int n, int threads) {
+  memset(pixels, 0, sizeof(float) * 4 * (size_t)n);
+  for (int i = 0; i < iter; i++)
+    render_image_impl(NULL, mc_array + (size_t)i * 0x4000 * 4,
+                      (const uint8_t*)opts_array + (size_t)i * OPTS_SIZE, pixels, n, 0, n, threads, NULL,
+                      NULL, sdf);
   if (argb) rmo_tonemap_image(pixels, opts_array, argb, n, 0, n);
 }
 

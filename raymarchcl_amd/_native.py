@@ -30,7 +30,7 @@ EXPORTS = [
     "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
-    "rm_render_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
+    "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
@@ -124,6 +124,8 @@ def lib():
     L.rm_tonemap_image.argtypes = [_vp, _vp, _vp, _vp, _i]
     L.rm_render_frame.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
     L.rm_tiles_per_part.argtypes = [_i, _i, _i]
+    L.rm_set_sdf_volume.argtypes = [_vp, _vp, _i, _i, _i]
+    L.rm_render_sdf_frame.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
     L.rm_frame_device.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     L.rm_resolve_device.argtypes = [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]
     L.rm_check_device_opts.argtypes = [_vp, _vp, _i, _i, _i]
@@ -265,6 +267,26 @@ class Context:
         check(lib().rm_tonemap_image(self._h, _np(pixels, np.float32, "pixels"),
                                      self._opts(bytes(opts)[:OPTS_BYTES]), argb.ctypes.data, n))
         return argb
+
+    # -- quality mode (not reference-equivalent; include/raymarch_hip.h) -----
+    def set_sdf_volume(self, sdf, vres):
+        rx, ry, rz = (int(v) for v in vres)
+        a = np.ascontiguousarray(sdf, dtype=np.float32).reshape(-1)
+        if a.size != rx * ry * rz:
+            raise ValueError(f"distance field has {a.size} values, vres says {rx}x{ry}x{rz}")
+        check(lib().rm_set_sdf_volume(self._h, a.ctypes.data, rx, ry, rz))
+
+    def render_sdf_frame(self, opts_array, mc_array, n, want_pixels=True, want_argb=True):
+        iters = len(bytes(opts_array)) // OPTS_BYTES
+        mc = np.ascontiguousarray(mc_array, dtype=np.float32).reshape(-1)
+        if mc.size != iters * TABLE_FLOATS:
+            raise ValueError("mc_array must hold one table per pass")
+        px = np.zeros(4 * n, dtype=np.float32) if want_pixels else None
+        argb = np.zeros(n, dtype=np.uint32) if want_argb else None
+        check(lib().rm_render_sdf_frame(self._h, self._opts(opts_array, iters), mc.ctypes.data, iters, n,
+                                        px.ctypes.data if want_pixels else None,
+                                        argb.ctypes.data if want_argb else None))
+        return px, argb
 
     def render_frame(self, opts_array, mc_array, n, want_pixels=True, want_argb=True):
         iters = len(bytes(opts_array)) // OPTS_BYTES

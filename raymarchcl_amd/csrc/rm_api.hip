@@ -68,7 +68,9 @@ struct rm_ctx {
   hipStream_t stream = nullptr;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
   DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf, lin_buf;
+  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf, lin_buf, sdf_buf;
+  int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
+  bool sdf_frame = false;                  // frame_on_device renders the distance field
   bool use_octants = false, force_octants = false;
   unsigned int oct_stride = 0;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
@@ -246,6 +248,15 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     const bool wave = c->wave_mode && c->use_accel;
     const bool need_same = wave || c->pass_pack > 0 || c->phase_mode;  // launches whose lanes share one record
     while (i1 < iter && iso_per_pass[i1] == iso_per_pass[i0] && (!need_same || same_as_prev[i1])) i1++;
+    if (c->sdf_frame) {  // quality mode: no derived structures
+      HIP_TRY(rmk::launch_render_sdf(c->stream, static_cast<const float*>(c->sdf_buf.p),
+                                     d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx, i1 - i0,
+                                     staging + (size_t)i0 * count * 4, n, tile_first, tile_stride,
+                                     c->pass_pack));
+      launches++;
+      i0 = i1;
+      continue;
+    }
     rmk::Accel accel;
     int rc = ensure_accel(c, iso_per_pass[i0], &accel);
     if (rc) return rc;
@@ -414,7 +425,8 @@ void rm_destroy(rm_ctx* c) {
   rmk::dump_work_stats();
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf, &c->queue_buf, &c->work_buf,
-                    &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o};
+                    &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sat_buf, &c->lin_buf,
+                    &c->sdf_buf};
   for (DevBuf* b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -630,6 +642,72 @@ int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, in
   rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
                        static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
                        static_cast<float*>(c->tile_buf.p), isos.data(), same.data(), recs.data());
+  if (rc) return rc;
+  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
+                              static_cast<const RmOpts*>(c->opts_buf.p),
+                              pixels_out ? static_cast<float*>(c->pix_buf.p) : nullptr,
+                              argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr, n));
+  if (pixels_out)
+    HIP_TRY(hipMemcpyAsync(pixels_out, c->pix_buf.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+  if (argb_out)
+    HIP_TRY(hipMemcpyAsync(argb_out, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+int rm_set_sdf_volume(rm_ctx* c, const float* sdf, int rx, int ry, int rz) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!sdf) return fail(RM_EINVAL, "sdf is NULL");
+  rc = check_res(rx, ry, rz);
+  if (rc) return rc;
+  if (rx < 2 || ry < 2 || rz < 2) return fail(RM_EINVAL, "a distance field needs at least 2 cells per axis");
+  const size_t bytes = (size_t)rx * ry * rz * 4;
+  HIP_TRY(c->sdf_buf.reserve(bytes));
+  HIP_TRY(hipMemcpyAsync(c->sdf_buf.p, sdf, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->sdf_rx = rx; c->sdf_ry = ry; c->sdf_rz = rz;
+  return RM_OK;
+}
+
+int rm_render_sdf_frame(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
+                        float* pixels_out, uint32_t* argb_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!opts_array || !mc_array) return fail(RM_EINVAL, "NULL buffer");
+  if (iter <= 0 || n < 0) return fail(RM_EINVAL, "iter = %d, n = %d", iter, n);
+  if (!c->sdf_rx) return fail(RM_ESTATE, "rm_set_sdf_volume has not been called");
+  std::vector<RmOpts> recs(iter);
+  memcpy(recs.data(), opts_array, (size_t)iter * RM_OPTS_BYTES);
+  for (int i = 0; i < iter; i++) {
+    const RmOpts& o = recs[i];
+    if (o.resolution[0] <= 0 || o.resolution[1] <= 0)
+      return fail(RM_EINVAL, "TRenderOpts.resolution = (%d,%d)", o.resolution[0], o.resolution[1]);
+    if (o.voxelRes[0] != c->sdf_rx || o.voxelRes[1] != c->sdf_ry || o.voxelRes[2] != c->sdf_rz)
+      return fail(RM_EINVAL, "TRenderOpts.voxelRes = (%d,%d,%d) does not match the distance field %dx%dx%d",
+                  o.voxelRes[0], o.voxelRes[1], o.voxelRes[2], c->sdf_rx, c->sdf_ry, c->sdf_rz);
+    if (o.numLights > 4) return fail(RM_EINVAL, "TRenderOpts.numLights = %d (max 4)", (int)o.numLights);
+  }
+  if (n == 0) return RM_OK;
+  HIP_TRY(c->opts_buf.reserve((size_t)iter * RM_OPTS_BYTES));
+  HIP_TRY(c->mc_buf.reserve((size_t)iter * RM_TABLE_FLOATS * 4));
+  HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
+  if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
+  HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts_array, (size_t)iter * RM_OPTS_BYTES,
+                         hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->mc_buf.p, mc_array, (size_t)iter * RM_TABLE_FLOATS * 4,
+                         hipMemcpyHostToDevice, c->stream));
+  const int resx = recs[0].resolution[0];
+  const int tiles = rmk::tiles_total(resx, n);
+  HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
+  std::vector<unsigned char> same;
+  records_same_as_prev(opts_array, iter, &same);
+  std::vector<int> isos(iter, 0);
+  c->sdf_frame = true;
+  rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
+                       static_cast<const float*>(c->mc_buf.p), resx, iter, n, 0, 1,
+                       static_cast<float*>(c->tile_buf.p), isos.data(), same.data(), recs.data());
+  c->sdf_frame = false;
   if (rc) return rc;
   HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
                               static_cast<const RmOpts*>(c->opts_buf.p),

@@ -75,6 +75,10 @@ hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, i
 long long bricked_bytes(int rx, int ry, int rz);
 hipError_t launch_brick(hipStream_t st, uint8_t* d_lin, int rx, int ry, int rz, uint8_t* d_bricked,
                         bool to_bricks);
+// quality mode: render_samples_kernel over a float distance field
+hipError_t launch_render_sdf(hipStream_t st, const float* d_sdf, const float* d_mc_all,
+                             const RmOpts* d_opts_all, int resx, int iter, float* d_staging, int n,
+                             int tile_first, int tile_stride, int pp_log2);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // rm_volgen.hip: the other volume producers of the reference, on the device
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);

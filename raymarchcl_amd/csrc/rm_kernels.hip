@@ -114,12 +114,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
 // trace the SAME pixel with different jitter follow almost the same control flow,
 // which is what a 64-wide SIMT machine wants -- neighbouring pixels of one pass
 // diverge far more (sky / surface / reflection) than passes of one pixel.
-template <bool ACCEL, int MINW>
+template <bool ACCEL, int MINW, bool SDFM = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
     const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
-    int tile_stride, int tiles_per_part, int pp_log2, int bpr, unsigned int oct_stride) {
+    int tile_stride, int tiles_per_part, int pp_log2, int bpr, unsigned int oct_stride,
+    const float* __restrict__ sdf = nullptr) {
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
   const int pass0 = blockIdx.y * pp;
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   const int pix = zy * 8 + zx;  // 0..63 within the tile, row-major 8x8
   const int id = lane_pixel((int)tile, pix, resx, g.tiles_x, n, 0, n);
   if (id < 0) return;
-  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32, oct_stride};
-  rmk::Tracer<false, ACCEL> tr(sc);
+  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32, oct_stride, sdf};
+  rmk::Tracer<false, ACCEL, SDFM> tr(sc);
   if (pp > 1) tr.set_pass(mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts_all[pass].time);
 #if RM_WAVE_SHARE
   static_assert(kWavesPerBlock == 1, "the shared phases use one LDS block per workgroup");
-  __shared__ float wave_lds[rmk::Tracer<false, ACCEL>::kWaveLdsFloats];
+  __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 1];
   const rmk::v3 col = ACCEL ? tr.shade_wave(id, wave_lds) : tr.shade(id);
 #else
   const rmk::v3 col = tr.shade(id);
@@ -554,6 +555,26 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
   else
     render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
                                                          n, tile_first, tile_stride, tpp, pp_log2, bpr, 0u);
+  return hipGetLastError();
+}
+
+// QUALITY MODE (not reference-equivalent): same grid and lane layout, distance field instead
+// of the byte grid
+hipError_t launch_render_sdf(hipStream_t st, const float* d_sdf, const float* mc_all,
+                             const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
+                             int tile_first, int tile_stride, int pp_log2) {
+  const TileGeom g = tile_geom(resx, n);
+  if (tile_stride < 1) tile_stride = 1;
+  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
+  const long long my_tiles =
+      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
+  if (my_tiles == 0 || iter <= 0) return hipSuccess;
+  while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;
+  const long long blocks = ((my_tiles << pp_log2) + kWavesPerBlock - 1) / kWavesPerBlock;
+  const dim3 grid((unsigned)blocks, (unsigned)(iter >> pp_log2));
+  render_samples_kernel<false, 4, true><<<grid, dim3(64 * kWavesPerBlock), 0, st>>>(
+      nullptr, nullptr, nullptr, reinterpret_cast<const float4*>(mc_all), d_opts_all,
+      reinterpret_cast<float4*>(staging), n, tile_first, tile_stride, tpp, pp_log2, 0, 0u, d_sdf);
   return hipGetLastError();
 }
 

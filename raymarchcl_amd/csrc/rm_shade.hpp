@@ -59,6 +59,7 @@ struct Scene {
   const uint8_t* __restrict__ dist;   // rm_accel.hip dist8, or nullptr
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
   unsigned int oct_stride = 0;        // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
+  const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
 };
 
 // ---- leaf routines shared by the straight (Tracer) and wave-scheduled
@@ -217,9 +218,12 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 #ifndef RM_INSIDE_TEST
 #define RM_INSIDE_TEST 1  // skip the slab test when the position is inside the box by a margin
 #endif
-template <bool COUNT, bool ACCEL = false>
+// SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
+// come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
+template <bool COUNT, bool ACCEL = false, bool SDFM = false>
 struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
+  static_assert(!(SDFM && (COUNT || ACCEL)), "the quality mode has no counters and no derived tables");
   const Scene& sc;
   // The pass a lane works on: its scatter table and its record's .time.  Defaults
   // to the scene's (uniform); set_pass() makes them per-lane so that one wavefront
@@ -295,12 +299,90 @@ struct Tracer {
     return normalize(n);
   }
 
+  // ---- QUALITY MODE (mirrors oracle/rm_restate.c sdf_* operation by operation) ----
+  // field value at a position inside (or on) the clip box: trilinear over cell centres
+  RM_DEV float sdf_sample(v3 q) {
+    const RmOpts& o = *sc.o;
+    const int rx = o.voxelRes[0], ry = o.voxelRes[1], rz = o.voxelRes[2];
+    const float ux = rmd::clamp_cl((q.x + o.voxelBounds[0]) * o.invVoxelScale[0] * (float)rx - 0.5f, 0.0f, (float)(rx - 1));
+    const float uy = rmd::clamp_cl((q.y + o.voxelBounds[1]) * o.invVoxelScale[1] * (float)ry - 0.5f, 0.0f, (float)(ry - 1));
+    const float uz = rmd::clamp_cl((q.z + o.voxelBounds[2]) * o.invVoxelScale[2] * (float)rz - 0.5f, 0.0f, (float)(rz - 1));
+    int ix = (int)ux, iy = (int)uy, iz = (int)uz;  // u >= 0: truncation = floor
+    ix = min(ix, rx - 2); iy = min(iy, ry - 2); iz = min(iz, rz - 2);
+    ix = max(ix, 0); iy = max(iy, 0); iz = max(iz, 0);
+    const float fx = ux - (float)ix, fy = uy - (float)iy, fz = uz - (float)iz;
+    const int x1 = ix + 1 < rx ? ix + 1 : ix, y1 = iy + 1 < ry ? iy + 1 : iy, z1 = iz + 1 < rz ? iz + 1 : iz;
+    const float* __restrict__ g = sc.sdf;
+    const size_t r00 = ((size_t)iz * ry + iy) * rx, r10 = ((size_t)iz * ry + y1) * rx,
+                 r01 = ((size_t)z1 * ry + iy) * rx, r11 = ((size_t)z1 * ry + y1) * rx;
+    const float a00 = g[r00 + ix] + (g[r00 + x1] - g[r00 + ix]) * fx;
+    const float a10 = g[r10 + ix] + (g[r10 + x1] - g[r10 + ix]) * fx;
+    const float a01 = g[r01 + ix] + (g[r01 + x1] - g[r01 + ix]) * fx;
+    const float a11 = g[r11 + ix] + (g[r11 + x1] - g[r11 + ix]) * fx;
+    const float b0 = a00 + (a10 - a00) * fy;
+    const float b1 = a01 + (a11 - a01) * fy;
+    return b0 + (b1 - b0) * fz;
+  }
+  // distance to the field's zero set from anywhere: outside the clip box the distance to
+  // the box is added to the value at the nearest point of the box
+  RM_DEV float sdf_volume(v3 p) {
+    const RmOpts& o = *sc.o;
+    const v3 q = V(rmd::clamp_cl(p.x, o.voxelBoundsMin[0], o.voxelBoundsMax[0]),
+                   rmd::clamp_cl(p.y, o.voxelBoundsMin[1], o.voxelBoundsMax[1]),
+                   rmd::clamp_cl(p.z, o.voxelBoundsMin[2], o.voxelBoundsMax[2]));
+    return sdf_sample(q) + length(p - q);
+  }
+  RM_DEV void scene_distance_sdf(v3 rpos, v3 dir, float& dist, float& code, v3& nrm) {
+    const RmOpts& o = *sc.o;
+    const float h = rpos.y + o.groundY;
+    float rd, rc;
+    if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
+    nrm = (rd < 1e5f) ? V(0.f, 1.f, 0.f) : -dir;
+    const float dv = sdf_volume(rpos);
+    if (dv < rd) {
+      rd = dv;
+      rc = 1.0f;
+      if (dv <= o.eps * 2.0f) {  // close enough to be the hit: gradient by central differences
+        const float e = o.voxelSize;
+        const v3 g = V(sdf_volume(V(rpos.x + e, rpos.y, rpos.z)) - sdf_volume(V(rpos.x - e, rpos.y, rpos.z)),
+                       sdf_volume(V(rpos.x, rpos.y + e, rpos.z)) - sdf_volume(V(rpos.x, rpos.y - e, rpos.z)),
+                       sdf_volume(V(rpos.x, rpos.y, rpos.z + e)) - sdf_volume(V(rpos.x, rpos.y, rpos.z - e)));
+        nrm = normalize(g);
+      } else {
+        nrm = -dir;
+      }
+    }
+    dist = rd;
+    code = rc;
+  }
+  // penumbra estimate along a light ray: min over the march of k * clearance / distance
+  RM_DEV float soft_shadow_sdf(v3 p, v3 ldir, float lmax) {
+    const RmOpts& o = *sc.o;
+    const float k = 1.0f / rmd::fmax_cl(o.lightScatter, 0.01f);
+    float res = 1.0f;
+    float t = 0.0f;
+    for (int i = 0; i < o.shadowIter; i++) {
+      const v3 q = mads(ldir, t, p);
+      const float h = q.y + o.groundY;
+      const float d = rmd::fmin_cl(h < 1e5f ? h : 1e5f, sdf_volume(q));
+      if (d <= o.eps * 0.5f) return 0.0f;
+      res = rmd::fmin_cl(res, k * d / (t + o.shadowBias));
+      t += rmd::fmax_cl(d, o.eps);
+      if (t >= lmax) break;
+    }
+    return rmd::clamp_cl(res, 0.0f, 1.0f);
+  }
+
   // distance estimate: renderer.cl:209-237
   // known_inside: the caller has established (slab-test filter) that rpos lies inside
   // the clip box by a margin; the reference's slab test then returns exactly +0.
   RM_DEV void scene_distance(v3 rpos, v3 dir, int steps, bool smooth, float& dist, float& code,
                              v3& nrm, bool known_inside = false) {
     const RmOpts& o = *sc.o;
+    if (SDFM) {
+      scene_distance_sdf(rpos, dir, dist, code, nrm);
+      return;
+    }
     if (COUNT) cnt.dts_calls++;
     const float h = rpos.y + o.groundY;
     float rd, rc;
@@ -481,8 +563,12 @@ struct Tracer {
     if (COUNT) cnt.rays++;
     RM_WS(ws_rays++);
     float dist = o.startDist;
+    // (the filter reasons about the clip box of the byte grid: off for the counting variant,
+    //  which must run the plain algorithm, and for the quality mode, whose field extends
+    //  beyond the box)
+    constexpr bool kFilter = !COUNT && !SDFM;
     BoxFilter flt{};
-    if (!COUNT) flt = make_filter(ro, rdir);
+    if (kFilter) flt = make_filter(ro, rdir);
     // Only the LAST estimate's position, code and normal survive the loop
     // (renderer.cl:244-246 overwrite them every turn), so the filtered turns -- the
     // large majority -- just remember that they were last; `last_t` is the distance
@@ -517,7 +603,7 @@ struct Tracer {
           g = h < 1e5f ? h : 1e5f;
           RM_WS(ws_iters++);
           RM_WS(wv_filt += wave_slots());
-          nw = !COUNT && surely_no_walk(flt, dist, g);
+          nw = kFilter && surely_no_walk(flt, dist, g);
           RM_WS(ws_filtered += nw ? 1u : 0u);
           go = nw & !((__builtin_fabsf(g) <= o.eps) | (dist >= maxDist));
           dist = go ? dist + g : dist;
@@ -528,7 +614,7 @@ struct Tracer {
       if (why != 1) break;
       float sd;
       RM_WS(wv_est += wave_slots());
-      const bool inside = !COUNT && surely_inside(flt, dist, g);
+      const bool inside = kFilter && surely_inside(flt, dist, g);
       scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
       last_kind = 1;
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
@@ -635,8 +721,9 @@ struct Tracer {
       const float att = 1.0f / d2;
       if (att > o.minLightAtt) {
         const v3 ldir = normalize(dl);
-        const float sh = shadow_term(mads(ldir, o.shadowBias, hitpos), ldir,
-                                     rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist));
+        const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
+        const float sh = SDFM ? soft_shadow_sdf(mads(ldir, o.shadowBias, hitpos), ldir, lmax)
+                              : shadow_term(mads(ldir, o.shadowBias, hitpos), ldir, lmax);
         if (sh > 0.0f) {
           const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
           diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));

@@ -131,3 +131,32 @@ def make_blob_volume(vres, seed=7, blobs=160, z_chunk=16):
         out = np.where(f > 1.0, 255, np.where(f > 0.93, np.where(stripe, 64, 128), 0))
         vox[z0 : z0 + zs.shape[0]] = out.astype(np.uint8)
     return vox.reshape(-1)
+
+
+def make_sdf_volume(vres, kind="gyroid"):
+    """float32 distance field [rz, ry, rx] over the volume box [-1, 1]^3 (cell centres) for the
+    QUALITY MODE (rm_set_sdf_volume; not a reference feature).  World units, negative inside.
+
+    ``gyroid``: shell of the reference's gyroid function (generators.clj:22-25, same scale as
+    make_gyroid_volume) cut to the slabs the byte volume fills, distance approximated by
+    value / gradient length (a conservative first-order estimate, scaled by 0.6);
+    ``torus``: a torus with a sphere above it (exact distances)."""
+    rx, ry, rz = _vres3(vres)
+    z, y, x = np.meshgrid((np.arange(rz) + 0.5) / rz * 2 - 1, (np.arange(ry) + 0.5) / ry * 2 - 1,
+                          (np.arange(rx) + 0.5) / rx * 2 - 1, indexing="ij")
+    if kind == "torus":
+        tor = np.sqrt((np.sqrt(x * x + z * z) - 0.55) ** 2 + (y + 0.3) ** 2) - 0.18
+        sph = np.sqrt(x * x + (y - 0.25) ** 2 + z * z) - 0.3
+        return np.minimum(tor, sph).astype(np.float32)
+    if kind != "gyroid":
+        raise KeyError(kind)
+    k = 2.56  # cells * 0.01 * 512 / res = world * res/2 * that: 256 cells span 2.56 * 2 radians ... per unit
+    X, Y, Z = (x + 1) * k + 0.3875, (y + 1) * k, (z + 1) * k
+    v = np.cos(X) * np.sin(Z) + np.cos(Y) * np.sin(X) + np.cos(Z) * np.sin(Y)
+    gx = -np.sin(X) * np.sin(Z) + np.cos(Y) * np.cos(X)
+    gy = -np.sin(Y) * np.sin(X) + np.cos(Z) * np.cos(Y)
+    gz = np.cos(X) * np.cos(Z) - np.sin(Z) * np.sin(Y)
+    g = np.sqrt(gx * gx + gy * gy + gz * gz) * k + 1e-3
+    shell = (np.abs(v) - 0.25) / g * 0.6
+    slab = np.abs(((z + 1) * 2) % 1.0 - 0.75) - 0.25  # keep z-slabs like (z & 0x3f) >= 32
+    return np.maximum(shell, slab / 2.0).astype(np.float32)

@@ -1,0 +1,57 @@
+"""QUALITY MODE (not the reference's algorithm): rm_render_sdf_frame against
+the CPU restatement of the same algorithm (oracle/rm_restate.c sdf_*), bit for bit -- both
+follow one arithmetic contract.  There is no reference to pin either to."""
+import numpy as np
+import pytest
+
+import raymarchcl_amd as rm
+from raymarchcl_amd import generators as gen
+from raymarchcl_amd import structs
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(w, h, it, vres, mat, theta, over=None):
+    recs = []
+    for i in range(it):
+        o = rm.render_options(width=w, height=h, vres=list(vres), t=i * 0.333, iter=it,
+                              eyepos=rm.compute_eyepos(theta, 2.25, 0.6), targetpos=[0, -0.4, 0], mat=mat)
+        o.update(over or {})
+        recs.append(structs.encode_bytes(o))
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("kind,vres,mat,theta,over", [
+    ("torus", (48, 48, 48), "metal", -45, None),
+    ("torus", (64, 40, 56), "orange-stripes", 30, dict(lightScatter=0.05)),
+    ("gyroid", (64, 64, 64), "metal2", 120, None),
+    ("torus", (32, 32, 32), "ao", 200, dict(aoIter=3, shadowIter=40)),
+])
+def test_sdf_frame_matches_its_restatement(native, oracle_mod, kind, vres, mat, theta, over):
+    w, h, it = 56, 40, 2
+    sdf = gen.make_sdf_volume(vres, kind)
+    assert sdf.shape == (vres[2], vres[1], vres[0])
+    opts = _records(w, h, it, vres, mat, theta, over)
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=31 + i) for i in range(it)])
+    n = w * h
+    want, want_argb = oracle_mod.render_sdf_frame(sdf, opts, mc, n)
+    with native.Context(0) as ctx:
+        ctx.set_sdf_volume(sdf, vres)
+        px, argb = ctx.render_sdf_frame(opts, mc, n)
+    bad = int((px.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, f"{bad} of {px.size} floats differ"
+    assert np.array_equal(argb, want_argb)
+    assert len(np.unique(argb)) > 50  # there is an object in view
+
+
+def test_sdf_api_errors(native):
+    with native.Context(0) as ctx:
+        opts = _records(16, 16, 1, (16, 16, 16), "metal", 0)
+        mc = gen.generate_scatter_offsets(0x4000, seed=1)
+        with pytest.raises(Exception):
+            ctx.render_sdf_frame(opts, mc, 256)            # no field yet
+        ctx.set_sdf_volume(np.ones((8, 8, 8), np.float32), (8, 8, 8))
+        with pytest.raises(Exception):
+            ctx.render_sdf_frame(opts, mc, 256)            # voxelRes mismatch
+        with pytest.raises(Exception):
+            ctx.set_sdf_volume(np.ones(8, np.float32), (1, 8, 1))
