@@ -21,7 +21,7 @@
 #include "rm_shade.hpp"
 #include "rm_wave.hpp"
 
-#ifdef RM_WORK_STATS
+#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
 // debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
 // over all lanes: samples, outer marches, their turns, filtered turns, voxel walks,
 // dist8 fetches, samples advanced, AO loops.  rmk::dump_work_stats() prints and resets.
@@ -163,6 +163,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
   const rmk::v3 col = tr.shade(id);
 #endif
   staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
+#ifdef RM_PHASE_CLOCK
+  for (int k = 0; k < 5; k++)
+    if (tr.ws_clk[k]) atomicAdd(&g_work_stats[32 + k], tr.ws_clk[k]);
+  if (tr.ws_now()) atomicAdd(&g_work_stats[37], 1ull);
+#endif
 #ifdef RM_WORK_STATS
   {
     unsigned int v[32] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
@@ -484,6 +489,19 @@ void dump_work_stats() {
   fprintf(stderr, "[work stats] samples advanced per sample: %.1f in walks that hit, %.1f in walks that do not "
                   "(%.1f of them after the walk's last fetch with value <= 1)\n",
           h[29] / n, h[30] / n, h[31] / n);
+#endif
+#ifdef RM_PHASE_CLOCK
+  {
+    unsigned long long h[48] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
+    const double waves = h[37] ? (double)h[37] : 1.0;
+    fprintf(stderr, "[phase clock] wave time by phase (shader clock ticks per wave): primary march %.0f, reflection "
+                    "marches %.0f, AO phases %.0f, shadow phases %.0f, shading arithmetic %.0f\n",
+            h[32] / waves, h[33] / waves, h[34] / waves, h[35] / waves, h[36] / waves);
+  }
+#endif
+#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
   unsigned long long z[48] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
 #endif

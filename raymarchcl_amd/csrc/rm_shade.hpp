@@ -253,6 +253,16 @@ struct Tracer {
 #else
 #define RM_WS(x) ((void)0)
 #endif
+#ifdef RM_PHASE_CLOCK
+  // debug build only (-DRM_PHASE_CLOCK, no other instrumentation): wave time per phase of
+  // shade_wave in shader clock ticks, charged to the wave's first active lane:
+  // 0 primary march, 1 reflection marches, 2 AO phases, 3 shadow phases, 4 shading arithmetic
+  unsigned long long ws_clk[5] = {0, 0, 0, 0, 0};
+  RM_DEV unsigned long long ws_now() {
+    const unsigned long long act = __ballot(1);
+    return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? (unsigned long long)clock64() : 0ull;
+  }
+#endif
   RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {}
   RM_DEV void set_pass(const float4* table_of_pass, float time_of_pass) {
     mc_ = table_of_pass;
@@ -1167,14 +1177,28 @@ struct Tracer {
                           v3 normal, v3 reflectCol) {
     const RmOpts& o = *sc.o;
     if (__ballot(active) == 0) return V(0.f, 0.f, 0.f);  // uniform
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c0 = ws_now();
+#endif
     const float ao = occlusion_wave(active, s, hitpos, normal);
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c1 = ws_now();
+    if (ws_c0 && ws_c1) ws_clk[2] += ws_c1 - ws_c0;
+#endif
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
       const float4 r = table(rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
       jit = V(r.x, r.y, r.z);
     }
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c2 = ws_now();
+#endif
     shadows_wave(active, hitpos, jit);
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c3 = ws_now();
+    if (ws_c2 && ws_c3) ws_clk[3] += ws_c3 - ws_c2;
+#endif
     v3 res = V(0.f, 0.f, 0.f);
     if (active) {
       v3 diff = sky(normal) * ao;
@@ -1203,6 +1227,10 @@ struct Tracer {
       res = V(out.x / fl, out.y / fl, out.z / fl);
     }
     wave_sync();  // results consumed before the next shared phase posts
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c4 = ws_now();
+    if (ws_c3 && ws_c4) ws_clk[4] += ws_c4 - ws_c3;
+#endif
     return res;
   }
 
@@ -1210,7 +1238,14 @@ struct Tracer {
   RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir) {
     const RmOpts& o = *sc.o;
     Hit h{};
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_p0 = ws_now();
+#endif
     march(ro, rdir, h, o.maxDist, o.maxIter, true);
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_p1 = ws_now();
+    if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
+#endif
     const bool hit = !(h.distance >= o.maxDist);
     Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
     v3 norm = V(0.f, 0.f, 0.f);
@@ -1230,6 +1265,9 @@ struct Tracer {
       for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
         if (__ballot(alive) == 0) break;         // uniform
         v3 from = V(0.f, 0.f, 0.f);
+#ifdef RM_PHASE_CLOCK
+        const unsigned long long ws_b0 = ws_now();
+#endif
         if (alive) {
           dir = reflect(dir, rh.normal);
           from = mads(dir, 0.0075f, rh.pos);
@@ -1237,6 +1275,10 @@ struct Tracer {
           march(from, dir, rh, o.maxDist, o.maxIter, false);  // bounce_colour(), renderer.cl:383-405
           RM_WS(ws_kind = 0);
         }
+#ifdef RM_PHASE_CLOCK
+        const unsigned long long ws_b1 = ws_now();
+        if (ws_b0 && ws_b1) ws_clk[1] += ws_b1 - ws_b0;
+#endif
         const bool bhit = alive && rh.objectID >= 0;
         Material bm{V(0.f, 0.f, 0.f), 0.f, 0.f};
         v3 brefl = V(0.f, 0.f, 0.f);
