@@ -383,11 +383,42 @@ struct Tracer {
     return rmd::clamp_cl(res, 0.0f, 1.0f);
   }
 
+  // ---- walks that only have to look as far as their result can depend on ----
+  // A caller that uses nothing but the DISTANCE of an estimate (AO probes, shadow marches: no
+  // normal, no material) gets min(ground term g, |rpos - hit| - voxelSize): a hit farther than
+  // g + voxelSize changes nothing.  More: an AO probe at distance d contributes
+  // 1 - max((d - sd)*aoAmp/d, 0) (renderer.cl:343), exactly 1 for every sd >= d (aoAmp >= 0,
+  // d > 0); a shadow march (renderer.cl:292-301) only reports whether it passes maxDist, and an
+  // estimate larger than the remaining distance + eps ends it the same way whatever its value.
+  // So such a walk only needs the samples within `reach` (+ voxelSize) of its start: sample k
+  // lies at least k * (smallest world step) away, which gives the sample count below; the +3
+  // covers the roundings of the reference's own distance evaluation many times over.  The
+  // samples that ARE walked are the reference's, so a hit within reach is bit-identical.
+  RM_DEV int walk_limit_for(float reach, int steps) {
+    const RmOpts& o = *sc.o;
+    // world advance per sample >= |dir| * min_axis(invVoxelScale * voxelBounds2) / (steps/2)
+    const float sc_min = fminf(fminf(__builtin_fabsf(o.invVoxelScale[0] * o.voxelBounds2[0]),
+                                     __builtin_fabsf(o.invVoxelScale[1] * o.voxelBounds2[1])),
+                               __builtin_fabsf(o.invVoxelScale[2] * o.voxelBounds2[2]));
+    const float step = 0.999f * sc_min / ((float)steps * 0.5f);
+    if (!(step > 1e-9f)) return 0x7fffffff;
+    const float k = (fmaxf(reach, 0.0f) + __builtin_fabsf(o.voxelSize)) / step + 3.0f;
+    return k < 1e9f ? (int)k : 0x7fffffff;  // (NaN reach: no limit)
+  }
+  // AO probe at distance d whose start is g above the ground
+  RM_DEV int ao_walk_limit(float d, float g, int steps) {
+    const RmOpts& o = *sc.o;
+    if (!(o.aoAmp >= 0.0f) || !(d > 0.0f)) return walk_limit_for(g, steps);
+    return walk_limit_for(fminf(d, g), steps);
+  }
+
   // distance estimate: renderer.cl:209-237
   // known_inside: the caller has established (slab-test filter) that rpos lies inside
   // the clip box by a margin; the reference's slab test then returns exactly +0.
+  // walk_limit: the caller has no use for a hit beyond that many samples (ao_walk_limit);
+  // accelerated path only -- the step vector still comes from `steps`.
   RM_DEV void scene_distance(v3 rpos, v3 dir, int steps, bool smooth, float& dist, float& code,
-                             v3& nrm, bool known_inside = false) {
+                             v3& nrm, bool known_inside = false, int walk_limit = 0x7fffffff) {
     const RmOpts& o = *sc.o;
     if (SDFM) {
       scene_distance_sdf(rpos, dir, dist, code, nrm);
@@ -425,6 +456,7 @@ struct Tracer {
       const float frx = (float)o.voxelRes[0], fry = (float)o.voxelRes[1], frz = (float)o.voxelRes[2];
       const int iso = o.isoVal;
       if (ACCEL) {
+        if (walk_limit < steps) steps = walk_limit;
         // cells per sample along the fastest axis, padded: bounds how many samples
         // certainly stay inside the empty neighbourhood dist8 reports
         const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
@@ -568,7 +600,10 @@ struct Tracer {
   RM_DEV bool surely_inside(const BoxFilter& f, float t, float g) {
     return (t >= f.in_lo) & (t < f.in_hi) & (g > __builtin_fmaf(__builtin_fabsf(t), 8e-6f, f.slack));
   }
-  RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth) {
+  // distance_only: the caller uses r.distance alone (shadow rays): walks may stop where a hit
+  // could no longer change it (walk_limit_for)
+  RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth,
+                    bool distance_only = false) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
     RM_WS(ws_rays++);
@@ -625,7 +660,9 @@ struct Tracer {
       float sd;
       RM_WS(wv_est += wave_slots());
       const bool inside = kFilter && surely_inside(flt, dist, g);
-      scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside);
+      int limit = 0x7fffffff;
+      if (ACCEL && distance_only) limit = walk_limit_for(fminf(g, (maxDist - dist) + o.eps), o.maxVoxelIter);
+      scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit);
       last_kind = 1;
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
       dist += sd;
@@ -682,7 +719,7 @@ struct Tracer {
     const int ws_saved = ws_kind;
     ws_kind = 2;
 #endif
-    march(p, ldir, h, lmax, sc.o->shadowIter, false);
+    march(p, ldir, h, lmax, sc.o->shadowIter, false, true);
     RM_WS(ws_kind = ws_saved);
     return rmd::step_cl(lmax, h.distance);
   }
@@ -710,7 +747,9 @@ struct Tracer {
       const int ws_saved = ws_kind;
       ws_kind = 3;
 #endif
-      scene_distance(mads(n, d, pos), n, o.maxVoxelIter / 2, false, sd, scode, nn);
+      const v3 rpos = mads(n, d, pos);
+      scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false,
+                     ACCEL ? ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2) : 0x7fffffff);
       RM_WS(ws_kind = ws_saved);
       ao *= 1.0f - rmd::fmax_cl((d - sd) * o.aoAmp / d, 0.0f);
     }
@@ -1111,7 +1150,9 @@ struct Tracer {
         const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, onrm));
         float sd, scode;
         v3 nn;
-        scene_distance(mads(n, d, opos), n, o.maxVoxelIter / 2, false, sd, scode, nn);
+        const v3 rpos = mads(n, d, opos);
+        scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false,
+                       ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2));
         lds_res(probe, owner) = sd;
       }
     }
@@ -1163,7 +1204,7 @@ struct Tracer {
           const v3 ldir = normalize(dlv);
           const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
           Hit h{};
-          march(mads(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false);
+          march(mads(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
           lds_res(light, owner) = h.distance;
         }
       }
