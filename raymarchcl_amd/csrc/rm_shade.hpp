@@ -215,6 +215,9 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 #ifndef RM_FASTDIV
 #define RM_FASTDIV 1      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
 #endif
+#ifndef RM_LAZY_NORMAL
+#define RM_LAZY_NORMAL 1  // primary / reflection marches: walks reach as far as the ground term; last turn repeated if cut
+#endif
 #ifndef RM_INSIDE_TEST
 #define RM_INSIDE_TEST 1  // skip the slab test when the position is inside the box by a margin
 #endif
@@ -394,13 +397,15 @@ struct Tracer {
   // lies at least k * (smallest world step) away, which gives the sample count below; the +3
   // covers the roundings of the reference's own distance evaluation many times over.  The
   // samples that ARE walked are the reference's, so a hit within reach is bit-identical.
-  RM_DEV int walk_limit_for(float reach, int steps) {
+  // (dir_len: length of the walk direction; reflected directions are not unit vectors because
+  //  the reference reflects about an un-normalised normal, renderer.cl:420, :434)
+  RM_DEV int walk_limit_for(float reach, int steps, float dir_len = 1.0f) {
     const RmOpts& o = *sc.o;
     // world advance per sample >= |dir| * min_axis(invVoxelScale * voxelBounds2) / (steps/2)
     const float sc_min = fminf(fminf(__builtin_fabsf(o.invVoxelScale[0] * o.voxelBounds2[0]),
                                      __builtin_fabsf(o.invVoxelScale[1] * o.voxelBounds2[1])),
                                __builtin_fabsf(o.invVoxelScale[2] * o.voxelBounds2[2]));
-    const float step = 0.999f * sc_min / ((float)steps * 0.5f);
+    const float step = 0.999f * sc_min * dir_len / ((float)steps * 0.5f);
     if (!(step > 1e-9f)) return 0x7fffffff;
     const float k = (fmaxf(reach, 0.0f) + __builtin_fabsf(o.voxelSize)) / step + 3.0f;
     return k < 1e9f ? (int)k : 0x7fffffff;  // (NaN reach: no limit)
@@ -418,7 +423,8 @@ struct Tracer {
   // walk_limit: the caller has no use for a hit beyond that many samples (ao_walk_limit);
   // accelerated path only -- the step vector still comes from `steps`.
   RM_DEV void scene_distance(v3 rpos, v3 dir, int steps, bool smooth, float& dist, float& code,
-                             v3& nrm, bool known_inside = false, int walk_limit = 0x7fffffff) {
+                             v3& nrm, bool known_inside = false, int walk_limit = 0x7fffffff,
+                             bool* cut = nullptr) {
     const RmOpts& o = *sc.o;
     if (SDFM) {
       scene_distance_sdf(rpos, dir, dist, code, nrm);
@@ -456,7 +462,8 @@ struct Tracer {
       const float frx = (float)o.voxelRes[0], fry = (float)o.voxelRes[1], frz = (float)o.voxelRes[2];
       const int iso = o.isoVal;
       if (ACCEL) {
-        if (walk_limit < steps) steps = walk_limit;
+        const bool limited = walk_limit < steps;
+        if (limited) steps = walk_limit;
         // cells per sample along the fastest axis, padded: bounds how many samples
         // certainly stay inside the empty neighbourhood dist8 reports
         const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
@@ -502,6 +509,7 @@ struct Tracer {
           ws_adds_lazy += (unsigned)(ws_steps0 - steps - ws_klast);
         }
 #endif
+        if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
           nrm = surf_normal(w, smooth);
@@ -633,6 +641,8 @@ struct Tracer {
     //   why: 1 = this turn needs the real estimate, 2 = out of turns,
     //        3 = stopped in a filtered turn, 4 = stopped in an estimated turn
     const int turns0 = maxSteps;
+    bool cut_last = false;
+    const float dir_len = (ACCEL && !COUNT) ? rmd::sqrt_rn(dot(rdir, rdir)) : 1.0f;
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
     for (;;) {
@@ -661,14 +671,28 @@ struct Tracer {
       RM_WS(wv_est += wave_slots());
       const bool inside = kFilter && surely_inside(flt, dist, g);
       int limit = 0x7fffffff;
-      if (ACCEL && distance_only) limit = walk_limit_for(fminf(g, (maxDist - dist) + o.eps), o.maxVoxelIter);
-      scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit);
+      // (`dist` counts in units of |rdir|: the remaining world distance is (maxDist - dist) * |rdir|)
+      if (ACCEL && distance_only)
+        limit = walk_limit_for(fminf(g, ((maxDist - dist) + o.eps) * fmaxf(dir_len, 1.0f)), o.maxVoxelIter, dir_len);
+      // Marches whose hit is used keep distance and code of a turn when a hit lies beyond the
+      // ground term, but take its NORMAL (renderer.cl:227-229 sets it before the union): only
+      // the last turn's normal survives, so walk as far as the ground term now and repeat the
+      // last turn without limit afterwards if its walk was cut (rare: the last turn of a ray
+      // is a filtered one or finds its hit close by)
+      if (ACCEL && RM_LAZY_NORMAL && !distance_only) limit = walk_limit_for(g, o.maxVoxelIter, dir_len);
+      cut_last = false;
+      scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
+                     &cut_last);
       last_kind = 1;
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
       dist += sd;
     }
     if (maxSteps != turns0) {  // at least one turn: renderer.cl:244-246 values of the last one
       r.pos = mads(rdir, last_t, ro);
+      if (ACCEL && RM_LAZY_NORMAL && !distance_only && last_kind == 1 && cut_last) {
+        float sd2, sc2;
+        scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
+      }
       if (last_kind == 0) {  // renderer.cl:211-212 for the ground / sky term
         const float h = (rdir.y * last_t + ro.y) + o.groundY;
         scode = h < 1e5f ? h : -1.0f;
