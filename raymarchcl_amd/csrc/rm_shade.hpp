@@ -394,8 +394,9 @@ struct Tracer {
   // d > 0); a shadow march (renderer.cl:292-301) only reports whether it passes maxDist, and an
   // estimate larger than the remaining distance + eps ends it the same way whatever its value.
   // So such a walk only needs the samples within `reach` (+ voxelSize) of its start: sample k
-  // lies at least k * (smallest world step) away, which gives the sample count below; the +3
-  // covers the roundings of the reference's own distance evaluation many times over.  The
+  // lies at least k * (smallest world step) away, which gives the sample count below; the +2
+  // (a hit beyond the limit is at least one whole step, >= 0.01 world units, past reach +
+  // voxelSize) covers the roundings of the reference's own distance evaluation, ~1e-6.  The
   // samples that ARE walked are the reference's, so a hit within reach is bit-identical.
   // (dir_len: length of the walk direction; reflected directions are not unit vectors because
   //  the reference reflects about an un-normalised normal, renderer.cl:420, :434)
@@ -407,7 +408,7 @@ struct Tracer {
                                __builtin_fabsf(o.invVoxelScale[2] * o.voxelBounds2[2]));
     const float step = 0.999f * sc_min * dir_len / ((float)steps * 0.5f);
     if (!(step > 1e-9f)) return 0x7fffffff;
-    const float k = (fmaxf(reach, 0.0f) + __builtin_fabsf(o.voxelSize)) / step + 3.0f;
+    const float k = (fmaxf(reach, 0.0f) + __builtin_fabsf(o.voxelSize)) / step + 2.0f;
     return k < 1e9f ? (int)k : 0x7fffffff;  // (NaN reach: no limit)
   }
   // AO probe at distance d whose start is g above the ground
