@@ -400,16 +400,25 @@ struct Tracer {
   // samples that ARE walked are the reference's, so a hit within reach is bit-identical.
   // (dir_len: length of the walk direction; reflected directions are not unit vectors because
   //  the reference reflects about an un-normalised normal, renderer.cl:420, :434)
-  RM_DEV int walk_limit_for(float reach, int steps, float dir_len = 1.0f) {
+  // samples per world unit of a walk, rounded UP by 0.2 % (hardware reciprocal: the limit is a
+  // bound, only its direction of error matters); 0 = unusable
+  RM_DEV float samples_per_unit(int steps, float dir_len = 1.0f) {
     const RmOpts& o = *sc.o;
     // world advance per sample >= |dir| * min_axis(invVoxelScale * voxelBounds2) / (steps/2)
     const float sc_min = fminf(fminf(__builtin_fabsf(o.invVoxelScale[0] * o.voxelBounds2[0]),
                                      __builtin_fabsf(o.invVoxelScale[1] * o.voxelBounds2[1])),
                                __builtin_fabsf(o.invVoxelScale[2] * o.voxelBounds2[2]));
-    const float step = 0.999f * sc_min * dir_len / ((float)steps * 0.5f);
-    if (!(step > 1e-9f)) return 0x7fffffff;
-    const float k = (fmaxf(reach, 0.0f) + __builtin_fabsf(o.voxelSize)) / step + 2.0f;
-    return k < 1e9f ? (int)k : 0x7fffffff;  // (NaN reach: no limit)
+    const float adv = sc_min * dir_len;
+    if (!(adv > 1e-6f)) return 0.0f;
+    return 1.002f * ((float)steps * 0.5f) * __builtin_amdgcn_rcpf(adv);
+  }
+  RM_DEV int walk_limit_from(float reach, float spu) {
+    const RmOpts& o = *sc.o;
+    const float k = (fmaxf(reach, 0.0f) + __builtin_fabsf(o.voxelSize)) * spu + 2.0f;
+    return ((spu > 0.0f) & (k < 1e9f)) ? (int)k : 0x7fffffff;  // (NaN reach: no limit)
+  }
+  RM_DEV int walk_limit_for(float reach, int steps, float dir_len = 1.0f) {
+    return walk_limit_from(reach, samples_per_unit(steps, dir_len));
   }
   // AO probe at distance d whose start is g above the ground
   RM_DEV int ao_walk_limit(float d, float g, int steps) {
@@ -643,7 +652,8 @@ struct Tracer {
     //        3 = stopped in a filtered turn, 4 = stopped in an estimated turn
     const int turns0 = maxSteps;
     bool cut_last = false;
-    const float dir_len = (ACCEL && !COUNT) ? rmd::sqrt_rn(dot(rdir, rdir)) : 1.0f;
+    const float dir_len = (ACCEL && !COUNT) ? __builtin_amdgcn_sqrtf(dot(rdir, rdir)) * 0.9999f : 1.0f;
+    const float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
     for (;;) {
@@ -674,13 +684,13 @@ struct Tracer {
       int limit = 0x7fffffff;
       // (`dist` counts in units of |rdir|: the remaining world distance is (maxDist - dist) * |rdir|)
       if (ACCEL && distance_only)
-        limit = walk_limit_for(fminf(g, ((maxDist - dist) + o.eps) * fmaxf(dir_len, 1.0f)), o.maxVoxelIter, dir_len);
+        limit = walk_limit_from(fminf(g, ((maxDist - dist) + o.eps) * fmaxf(dir_len, 1.0f) * 1.001f), spu);
       // Marches whose hit is used keep distance and code of a turn when a hit lies beyond the
       // ground term, but take its NORMAL (renderer.cl:227-229 sets it before the union): only
       // the last turn's normal survives, so walk as far as the ground term now and repeat the
       // last turn without limit afterwards if its walk was cut (rare: the last turn of a ray
       // is a filtered one or finds its hit close by)
-      if (ACCEL && RM_LAZY_NORMAL && !distance_only) limit = walk_limit_for(g, o.maxVoxelIter, dir_len);
+      if (ACCEL && RM_LAZY_NORMAL && !distance_only) limit = walk_limit_from(g, spu);
       cut_last = false;
       scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
                      &cut_last);
