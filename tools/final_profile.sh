@@ -23,5 +23,7 @@ for w in c1 c3 c4 c5; do python bench.py --workload $w --steps 5 --warmup 1 --no
 RAYMARCH_OCTANTS=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_no_octants.json
 python tools/part_timing.py --frames-in-flight 2 --reps 30 > $OUT/part_timing.txt 2>&1
 python tools/work_stats.py c2 > $OUT/work_stats.txt 2>&1
+python tools/work_stats.py c2 --clock >> $OUT/work_stats.txt 2>&1
+python tools/sdf_bench.py > $OUT/sdf_bench.txt 2>&1
 rm -rf $OUT/pmc/p*/pmc_results.db
 head -c 600 $OUT/bench_line.json; echo; tail -3 $OUT/part_timing.txt; head -5 $OUT/kernel_stats.txt
