@@ -170,6 +170,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
 #endif
 #ifdef RM_WORK_STATS
   {
+    atomicAdd(&g_work_stats[40], (unsigned long long)tr.ws_pairs);
+    atomicAdd(&g_work_stats[41], (unsigned long long)tr.ws_pairs_back);
+    atomicAdd(&g_work_stats[42], (unsigned long long)tr.ws_pairs_dark);
     unsigned int v[32] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
                           tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
     for (int k = 0; k < 4; k++) {
@@ -489,6 +492,8 @@ void dump_work_stats() {
   fprintf(stderr, "[work stats] samples advanced per sample: %.1f in walks that hit, %.1f in walks that do not "
                   "(%.1f of them after the walk's last fetch with value <= 1)\n",
           h[29] / n, h[30] / n, h[31] / n);
+  fprintf(stderr, "[work stats] (hit, light) pairs per sample %.2f: %.1f%% face away from the light, %.1f%% of all have "
+                  "no specular term either\n", h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1));
 #endif
 #ifdef RM_PHASE_CLOCK
   {

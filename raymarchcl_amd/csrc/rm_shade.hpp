@@ -247,6 +247,7 @@ struct Tracer {
   int ws_kind = 0;
   unsigned int ws_k_walks[4] = {0, 0, 0, 0}, ws_k_fetch[4] = {0, 0, 0, 0}, ws_k_slots[4] = {0, 0, 0, 0};
   unsigned int ws_dhist[7] = {0, 0, 0, 0, 0, 0, 0};  // fetched dist8 value: 0 (hit), 1, 2, 3, 4-7, 8+; [6] = last value
+  unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
   RM_DEV unsigned int wave_slots() {
     const unsigned long long act = __ballot(1);
@@ -1290,6 +1291,13 @@ struct Tracer {
           const v3 ldir = normalize(dl);
           const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
           const float sh = rmd::step_cl(lmax, lds_res(i, lane));
+#ifdef RM_WORK_STATS
+          ws_pairs++;
+          if (rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f) {
+            ws_pairs_back++;
+            if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
+          }
+#endif
           if (sh > 0.0f) {
             const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
             diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
