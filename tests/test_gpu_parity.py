@@ -270,3 +270,57 @@ def test_shared_secondary_rays_against_oracle(oracle_mod, native, name, over):
     assert _eq(px, want), (name, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
     assert np.array_equal(argb, want_argb)
     assert len(np.unique(argb)) > 20
+
+
+@pytest.mark.parametrize("name,over", [
+    ("ao_amp_negative", dict(aoAmp=-0.3)),               # farther hits matter: no AO walk limit from d
+    ("ao_step_zero", dict(aoStepDist=0.0)),              # d = 0: division 0/0 in the reference's formula
+    ("ao_step_negative", dict(aoStepDist=-0.04)),
+    ("ao_step_large", dict(aoStepDist=0.6)),             # probes start outside the box
+    ("voxel_size_negative", dict(voxelSize=-0.02)),
+    ("voxel_size_large", dict(voxelSize=0.2)),
+    ("few_samples_odd", dict(maxVoxelIter=33)),
+    ("many_samples", dict(maxVoxelIter=400)),
+    ("big_eps", dict(eps=0.08)),
+    ("shadow_bias_large", dict(shadowBias=0.6)),
+    ("ground_high", dict(groundY=0.2)),                  # ground plane cuts through the volume
+    ("ground_far", dict(groundY=40.0)),
+    ("max_dist_short", dict(maxDist=2.0)),               # marches end on distance inside the scene
+    ("few_turns", dict(maxIter=6, shadowIter=3)),        # marches run out of turns
+    ("start_dist", dict(startDist=0.7)),
+    ("anisotropic_scale", dict(invVoxelScale=[0.5, 0.4, 0.625], voxelBounds=[1.0, 1.25, 0.8],
+                               voxelBounds2=[2.0, 2.5, 1.6], voxelBoundsMin=[-0.99, -1.2375, -0.792],
+                               voxelBoundsMax=[0.99, 1.2375, 0.792])),
+])
+def test_walk_limits_with_unusual_records(oracle_mod, native, name, over):
+    """The walks of AO probes, shadow marches and (lazily) primary / reflection marches stop
+    where a hit can no longer change their result (rm_shade.hpp walk_limit_from): records that
+    stress the assumptions behind that bound must still give the oracle's bits."""
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen
+    from raymarchcl_amd import structs
+
+    w, h, it, vres = 48, 40, 2, 64
+    vox = scenes.volume("gyroid", vres)
+    recs = []
+    for i in range(it):
+        o = rm.render_options(width=w, height=h, vres=[vres] * 3, t=i * 0.333, iter=it,
+                              eyepos=rm.compute_eyepos(-60, 2.2, 0.5), targetpos=[0, -0.3, 0], mat="metal")
+        o.update(over)
+        recs.append(structs.encode_bytes(o))
+    opts = b"".join(recs)
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=300 + i) for i in range(it)])
+    n = w * h
+    want = np.zeros(4 * n, np.float32)
+    mask = np.zeros(n, np.uint8)
+    for i in range(it):
+        oracle_mod.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], want, n=n, undefined_mask=mask)
+    with native.Context(0) as ctx:
+        ctx.set_volume(vox, (vres,) * 3)
+        px, _ = ctx.render_frame(opts, mc, n)
+    ok = np.repeat(mask == 0, 4)
+    a, b = px.view(np.uint32)[ok], want.view(np.uint32)[ok]
+    nan = np.isnan(want[ok])
+    assert np.array_equal(a[~nan], b[~nan]), (name, int((a[~nan] != b[~nan]).sum()))
+    assert np.isnan(px[ok][nan]).all()
+    assert ok.mean() > 0.5
