@@ -159,15 +159,34 @@ class FrameRenderer:
         with torch.cuda.stream(slot.stream):
             slot.ctx.frame_device(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
                                   self.width, slot.d_tiles.data_ptr(), self.rank, self.world)
-            allt = gather_tiles(slot.d_tiles, self.rank, self.world, group=self.group)
+            allt = self._gather(slot)
             if self.rank == 0:
                 slot.ctx.resolve_device(allt.data_ptr(), self.world, self.d_opts.data_ptr(), self.n,
                                         self.width,
                                         slot.d_pixels.data_ptr() if slot.d_pixels is not None else None,
                                         slot.d_argb.data_ptr() if slot.d_argb is not None else None)
-                if allt is not slot.d_tiles:
-                    allt.record_stream(slot.stream)
         return slot.d_pixels, slot.d_argb
+
+    def _gather(self, slot):
+        """The frame's one collective.  With RCCL the root's receive buffer and its per-rank
+        views are made once per slot (a frame of an 8-GPU share lasts well under a millisecond:
+        per-frame allocations and list building would show); other backends go through
+        gather_tiles()."""
+        if self.world == 1:
+            return slot.d_tiles
+        import torch.distributed as dist
+
+        if dist.get_backend(self.group) != "nccl":
+            return gather_tiles(slot.d_tiles, self.rank, self.world, group=self.group)
+        if self.rank == 0:
+            if getattr(slot, "d_all", None) is None:
+                slot.d_all = self.torch.empty(self.world * slot.d_tiles.numel(), dtype=slot.d_tiles.dtype,
+                                              device=self.device)
+                slot.chunks = list(slot.d_all.view(self.world, -1).unbind(0))
+            dist.gather(slot.d_tiles, gather_list=slot.chunks, dst=0, group=self.group)
+            return slot.d_all
+        dist.gather(slot.d_tiles, gather_list=None, dst=0, group=self.group)
+        return None
 
     def close(self):
         self.torch.cuda.synchronize(self.device)
