@@ -38,7 +38,7 @@ WORKLOADS = {
                vres=256, w=1280, h=720, spp=16, mat="orange-stripes", dof=0.025),
     "c1": dict(desc="64^3 gyroid, 256x256, 1 spp, :orange-stripes", vol="gyroid", vres=64, w=256,
                h=256, spp=1, mat="orange-stripes"),
-    "c3": dict(desc="512^3 procedural blob volume (bunny stand-in), 1920x1080, 16 spp, :metal",
+    "c3": dict(desc="512^3 procedural blob volume (bunny stand-in, ~8 % fill), 1920x1080, 16 spp, :metal",
                vol="blobs", vres=512, w=1920, h=1080, spp=16, mat="metal"),
     "c4": dict(desc="256^3 gyroid, 3840x2160, 64 spp + DOF 0.025, :orange-stripes", vol="gyroid",
                vres=256, w=3840, h=2160, spp=64, mat="orange-stripes", dof=0.025),
@@ -61,7 +61,7 @@ def build_inputs(wl):
         with _native.Context(int(os.environ.get("LOCAL_RANK", "0"))) as gctx:
             vox = gctx.make_gyroid_volume(vres)
     else:
-        vox = gen.make_blob_volume(vres)
+        vox = gen.make_blob_volume(vres, radius=(0.01, 0.03))
     extra = {k: wl[k] for k in ("dof",) if k in wl}
     opts = b"".join(
         structs.encode_bytes(rm.render_options(

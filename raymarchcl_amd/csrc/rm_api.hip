@@ -71,7 +71,7 @@ struct rm_ctx {
   DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf, lin_buf, sdf_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool sdf_frame = false;                  // frame_on_device renders the distance field
-  bool use_octants = false, force_octants = false;
+  bool use_octants = false;
   unsigned int oct_stride = 0;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
@@ -131,12 +131,9 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   if ((long long)c->ry * c->rz >= (1 << 24) || c->rx >= (1 << 24)) return RM_OK;
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
   if (c->accel_iso != iso) {
-    // directional tables behind dist8: by default only while all 9 tables fit the 256 MB
-    // Infinity Cache (measured: 256^3 -10 % frame time, 512^3 +6 %: the eight-fold working
-    // set then misses more than the longer skips save); RAYMARCH_OCTANTS=1 forces them
-    // for anything that stays within 32-bit offsets
-    const bool oct = c->use_octants && vox * 9 < 0xffffffffull &&
-                     (c->force_octants || vox * 9 <= (256ull << 20));
+    // directional tables behind dist8 whenever all 9 tables stay within 32-bit offsets (up to
+    // ~780^3; measured -10 % frame time at 256^3, -12 % at 512^3 with 8 % fill)
+    const bool oct = c->use_octants && vox * 9 < 0xffffffffull;
     const int tables = oct ? 9 : 1;
 #if RM_BRICKS
     // tables are built row-major in lin_buf, then re-laid in 8x4x4 bricks
@@ -391,7 +388,6 @@ int rm_create(int device_id, rm_ctx** out) {
   c->use_accel = !(na && na[0] == '1');
   const char* oc = getenv("RAYMARCH_OCTANTS");
   c->use_octants = !(oc && oc[0] == '0');  // directional tables: on unless RAYMARCH_OCTANTS=0
-  c->force_octants = oc && oc[0] == '1';   // ... =1: also for volumes beyond the cache-fit limit
   const char* km = getenv("RAYMARCH_KERNEL");
   c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
   c->stream_mode = km && strcmp(km, "stream") == 0;  // experimental task-queue pipeline

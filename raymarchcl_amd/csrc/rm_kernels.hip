@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
 #endif
 #ifdef RM_WORK_STATS
   {
+    atomicAdd(&g_work_stats[43], (unsigned long long)tr.ws_redo);
     atomicAdd(&g_work_stats[40], (unsigned long long)tr.ws_pairs);
     atomicAdd(&g_work_stats[41], (unsigned long long)tr.ws_pairs_back);
     atomicAdd(&g_work_stats[42], (unsigned long long)tr.ws_pairs_dark);
@@ -493,7 +494,8 @@ void dump_work_stats() {
                   "(%.1f of them after the walk's last fetch with value <= 1)\n",
           h[29] / n, h[30] / n, h[31] / n);
   fprintf(stderr, "[work stats] (hit, light) pairs per sample %.2f: %.1f%% face away from the light, %.1f%% of all have "
-                  "no specular term either\n", h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1));
+                  "no specular term either; last turn repeated for its normal in %.3f marches per sample\n",
+          h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1), h[43] / n);
 #endif
 #ifdef RM_PHASE_CLOCK
   {

@@ -247,6 +247,7 @@ struct Tracer {
   int ws_kind = 0;
   unsigned int ws_k_walks[4] = {0, 0, 0, 0}, ws_k_fetch[4] = {0, 0, 0, 0}, ws_k_slots[4] = {0, 0, 0, 0};
   unsigned int ws_dhist[7] = {0, 0, 0, 0, 0, 0, 0};  // fetched dist8 value: 0 (hit), 1, 2, 3, 4-7, 8+; [6] = last value
+  unsigned int ws_redo = 0;  // marches whose last turn was repeated for its normal
   unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
   RM_DEV unsigned int wave_slots() {
@@ -702,6 +703,7 @@ struct Tracer {
     if (maxSteps != turns0) {  // at least one turn: renderer.cl:244-246 values of the last one
       r.pos = mads(rdir, last_t, ro);
       if (ACCEL && RM_LAZY_NORMAL && !distance_only && last_kind == 1 && cut_last) {
+        RM_WS(ws_redo++);
         float sd2, sc2;
         scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
       }

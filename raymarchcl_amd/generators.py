@@ -105,18 +105,21 @@ def make_terrain(vres):
     return vox.reshape(-1)
 
 
-def make_blob_volume(vres, seed=7, blobs=160, z_chunk=16):
+def make_blob_volume(vres, seed=7, blobs=160, z_chunk=16, radius=None):
     """Seeded procedural stand-in for the reference's mesh-derived volumes.
 
     Union of metaballs inside the unit cube: field ``f = sum r_i^2 / |p-c_i|^2``;
     ``f > 1`` -> 255 (solid), a thin band just outside -> 64/128 in alternating
-    x-stripes (mimics the gyroid's material bands).  Fill is ~5-10 %.
+    x-stripes (mimics the gyroid's material bands).  ``radius=(lo, hi)`` sets the blob radii:
+    the default (0.03, 0.08) merges the blobs into one porous mass (93 % solid; what the golden
+    fixtures use), (0.01, 0.03) gives separate bodies at ~8 % fill -- the bench's stand-in for
+    the reference's mesh-derived volumes.
     """
     rx, ry, rz = _vres3(vres)
     u = _uniform01(seed, 4 * blobs).reshape(blobs, 4)
     c = 0.15 + 0.7 * u[:, :3]
     c[:, 1] = 0.05 + 0.55 * u[:, 1]
-    r2 = (0.03 + 0.05 * u[:, 3]) ** 2
+    r2 = ((0.03 + 0.05 * u[:, 3]) if radius is None else (radius[0] + (radius[1] - radius[0]) * u[:, 3])) ** 2
     vox = np.zeros((rz, ry, rx), dtype=np.uint8)
     xs = ((np.arange(rx) + 0.5) / rx)[None, None, :]
     ys = ((np.arange(ry) + 0.5) / ry)[None, :, None]
