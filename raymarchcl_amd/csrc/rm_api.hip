@@ -72,7 +72,7 @@ struct rm_ctx {
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool sdf_frame = false;                  // frame_on_device renders the distance field
   bool use_octants = false;
-  unsigned int oct_stride = 0;
+  unsigned long long oct_stride = 0;
   int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
   long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
   int phase_mode = 0;      // RAYMARCH_KERNEL=phases: chain / point rays / shading as three launches
@@ -131,9 +131,9 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   if ((long long)c->ry * c->rz >= (1 << 24) || c->rx >= (1 << 24)) return RM_OK;
   const size_t vox = (size_t)c->rx * c->ry * c->rz;
   if (c->accel_iso != iso) {
-    // directional tables behind dist8 whenever all 9 tables stay within 32-bit offsets (up to
-    // ~780^3; measured -10 % frame time at 256^3, -12 % at 512^3 with 8 % fill)
-    const bool oct = c->use_octants && vox * 9 < 0xffffffffull;
+    // directional tables behind dist8 (measured -10 % frame time at 256^3, -12 % at 512^3 with
+    // 8 % fill); table offsets are 64-bit, nine 1024^3 tables span 9 GiB
+    const bool oct = c->use_octants;
     const int tables = oct ? 9 : 1;
 #if RM_BRICKS
     // tables are built row-major in lin_buf, then re-laid in 8x4x4 bricks
@@ -155,13 +155,13 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
       HIP_TRY(c->sat_buf.reserve(sat));
       HIP_TRY(rmk::build_octants(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso, lin,
                                  static_cast<uint32_t*>(c->sat_buf.p)));
-      c->oct_stride = (unsigned int)vox;
+      c->oct_stride = vox;
     }
 #if RM_BRICKS
     for (int t = 0; t < tables; t++)
       HIP_TRY(rmk::launch_brick(c->stream, lin + (size_t)t * vox, c->rx, c->ry, c->rz,
                                 static_cast<uint8_t*>(c->dist_buf.p) + (size_t)t * bb, true));
-    if (oct) c->oct_stride = (unsigned int)bb;
+    if (oct) c->oct_stride = bb;
 #endif
     c->accel_iso = iso;
   }

@@ -21,7 +21,7 @@ struct Accel {  // nullptrs = not available: the kernels then run the plain fixe
   const uint8_t* dist = nullptr;
   const uint32_t* surf = nullptr;
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
-  unsigned int oct_stride = 0;
+  unsigned long long oct_stride = 0;
 };
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
     const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
-    int tile_stride, int tiles_per_part, int pp_log2, int bpr, unsigned int oct_stride,
+    int tile_stride, int tiles_per_part, int pp_log2, int bpr, unsigned long long oct_stride,
     const float* __restrict__ sdf = nullptr) {
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
@@ -579,7 +579,7 @@ hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel
     }
   else
     render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
-                                                         n, tile_first, tile_stride, tpp, pp_log2, bpr, 0u);
+                                                         n, tile_first, tile_stride, tpp, pp_log2, bpr, 0ull);
   return hipGetLastError();
 }
 
@@ -599,7 +599,7 @@ hipError_t launch_render_sdf(hipStream_t st, const float* d_sdf, const float* mc
   const dim3 grid((unsigned)blocks, (unsigned)(iter >> pp_log2));
   render_samples_kernel<false, 4, true><<<grid, dim3(64 * kWavesPerBlock), 0, st>>>(
       nullptr, nullptr, nullptr, reinterpret_cast<const float4*>(mc_all), d_opts_all,
-      reinterpret_cast<float4*>(staging), n, tile_first, tile_stride, tpp, pp_log2, 0, 0u, d_sdf);
+      reinterpret_cast<float4*>(staging), n, tile_first, tile_stride, tpp, pp_log2, 0, 0ull, d_sdf);
   return hipGetLastError();
 }
 

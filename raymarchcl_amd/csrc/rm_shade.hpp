@@ -58,7 +58,7 @@ struct Scene {
   const RmOpts* __restrict__ o;
   const uint8_t* __restrict__ dist;   // rm_accel.hip dist8, or nullptr
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
-  unsigned int oct_stride = 0;        // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
+  unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
   const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
 };
 
@@ -148,7 +148,7 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // j = 1 + floor(0.98 * (d-1) / s)   (inv_s = 0.98 / s; the 2 % absorb the <= 0.01
 // cell of accumulated rounding drift and the rounding of p*res).
 RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
-                     float inv_s, int* cell_out, unsigned int table_off = 0, unsigned int* dhist = nullptr) {
+                     float inv_s, int* cell_out, unsigned long long table_off = 0, unsigned int* dhist = nullptr) {
   const int qx = rmd::convert_int_sat(p.x * (float)o.voxelRes[0]);
   const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
   const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
@@ -482,7 +482,7 @@ struct Tracer {
                               __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
         // directional table of this walk (a walk never moves against the signs of delta)
-        unsigned int table_off = 0;
+        unsigned long long table_off = 0;  // 64-bit: nine 1024^3 tables span 9 GiB
         if (sc.oct_stride) {
           const unsigned int oct = (delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u);
           table_off = (oct + 1u) * sc.oct_stride;

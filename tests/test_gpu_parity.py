@@ -324,3 +324,28 @@ def test_walk_limits_with_unusual_records(oracle_mod, native, name, over):
     assert np.array_equal(a[~nan], b[~nan]), (name, int((a[~nan] != b[~nan]).sum()))
     assert np.isnan(px[ok][nan]).all()
     assert ok.mean() > 0.5
+
+
+def test_tables_beyond_4_gib(native, oracle_mod):
+    """1024^3: the nine distance tables span 9 GiB, so the directional ones are reached
+    through 64-bit offsets.  Volume generated on the device, one small pass == oracle."""
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen
+    from raymarchcl_amd import structs
+
+    res, w, h = 1024, 40, 30
+    with native.Context(0) as ctx:
+        vox = ctx.make_gyroid_volume(res)          # resident + host copy (1 GiB)
+        opts = structs.encode_bytes(rm.render_options(
+            width=w, height=h, vres=[res] * 3, t=0.0, iter=1, eyepos=rm.compute_eyepos(-45, 2.25, 0.35),
+            targetpos=[0, -0.4, 0], mat="metal"))
+        mc = gen.generate_scatter_offsets(0x4000, seed=4242)
+        n = w * h
+        px, _ = ctx.render_frame(opts, mc[None, :], n)
+        octs = None
+    want = np.zeros(4 * n, np.float32)
+    mask = np.zeros(n, np.uint8)
+    oracle_mod.render_image(vox, mc, opts, want, n=n, undefined_mask=mask)
+    ok = np.repeat(mask == 0, 4)
+    assert np.array_equal(px.view(np.uint32)[ok], want.view(np.uint32)[ok])
+    assert ok.mean() > 0.9 and len(np.unique(px)) > 100
