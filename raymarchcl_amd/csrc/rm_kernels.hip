@@ -171,6 +171,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
 #ifdef RM_WORK_STATS
   {
     atomicAdd(&g_work_stats[43], (unsigned long long)tr.ws_redo);
+    for (int k = 0; k < 4; k++) atomicAdd(&g_work_stats[44 + k], (unsigned long long)tr.ws_k_nohit[k]);
+    atomicAdd(&g_work_stats[38], (unsigned long long)(tr.ws_k_one[0] + tr.ws_k_one[1]));
+    atomicAdd(&g_work_stats[39], (unsigned long long)tr.ws_k_one[2]);
     atomicAdd(&g_work_stats[40], (unsigned long long)tr.ws_pairs);
     atomicAdd(&g_work_stats[41], (unsigned long long)tr.ws_pairs_back);
     atomicAdd(&g_work_stats[42], (unsigned long long)tr.ws_pairs_dark);
@@ -496,6 +499,9 @@ void dump_work_stats() {
   fprintf(stderr, "[work stats] (hit, light) pairs per sample %.2f: %.1f%% face away from the light, %.1f%% of all have "
                   "no specular term either; last turn repeated for its normal in %.3f marches per sample\n",
           h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1), h[43] / n);
+  fprintf(stderr, "[work stats] walks without a hit per sample: primary %.2f, reflection %.2f, shadow %.2f, AO %.2f; "
+                  "ended by their first fetch: primary+reflection %.2f, shadow %.2f\n",
+          h[44] / n, h[45] / n, h[46] / n, h[47] / n, h[38] / n, h[39] / n);
 #endif
 #ifdef RM_PHASE_CLOCK
   {

@@ -247,6 +247,7 @@ struct Tracer {
   int ws_kind = 0;
   unsigned int ws_k_walks[4] = {0, 0, 0, 0}, ws_k_fetch[4] = {0, 0, 0, 0}, ws_k_slots[4] = {0, 0, 0, 0};
   unsigned int ws_dhist[7] = {0, 0, 0, 0, 0, 0, 0};  // fetched dist8 value: 0 (hit), 1, 2, 3, 4-7, 8+; [6] = last value
+  unsigned int ws_k_nohit[4] = {0, 0, 0, 0}, ws_k_one[4] = {0, 0, 0, 0};  // walks without a hit; of those, ended by their first fetch
   unsigned int ws_redo = 0;  // marches whose last turn was repeated for its normal
   unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
@@ -497,6 +498,7 @@ struct Tracer {
 #ifdef RM_WORK_STATS
         const int ws_steps0 = steps;
         int ws_klast = 0;
+        unsigned int ws_nf = 0;
 #endif
         do {
           RM_WS(ws_lookups++);
@@ -504,6 +506,7 @@ struct Tracer {
           RM_WS(ws_k_slots[ws_kind] += wave_slots());
           RM_WS(ws_k_fetch[ws_kind]++);
           RM_WS(ws_steps += (unsigned)steps);
+          RM_WS(ws_nf++);
 #ifdef RM_WORK_STATS
           r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist);
 #else
@@ -518,6 +521,8 @@ struct Tracer {
         if (r == 1) ws_adds_hit += (unsigned)(ws_steps0 - steps);
         else {
           ws_adds_nohit += (unsigned)(ws_steps0 - steps);
+          ws_k_nohit[ws_kind]++;
+          if (ws_nf == 1) ws_k_one[ws_kind]++;
           ws_adds_lazy += (unsigned)(ws_steps0 - steps - ws_klast);
         }
 #endif
