@@ -233,12 +233,12 @@ def main():
                                     "note": "rm_render_frame with host buffers (PCIe-inclusive)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vox, opts, mc, n, spp, args.cpu_passes)
+    if rank == 0:
+        print(json.dumps(out), flush=True)  # before the teardown: the line must not depend on it
     fr.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(vox, opts, mc, n, spp, passes):
