@@ -109,11 +109,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    # BENCH_ONE_DEVICE=1 (rehearsal of the N > 1 path on a single-GPU box): every rank on
+    # cuda:0 and gloo instead of RCCL, which cannot place two ranks on one device
+    rehearsal = os.environ.get("BENCH_ONE_DEVICE", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from raymarchcl_amd import _native, multigpu
 
@@ -144,13 +152,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fr.render()
-        if rank == 0 and world == 1:
-            pass
     sync_all()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -203,7 +209,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]],
-                       "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + ((", gloo gather through the host (BENCH_ONE_DEVICE rehearsal: all ranks on one GPU)" if rehearsal
+                                     else ", RCCL gather to rank 0") if world > 1 else ""),
                        "frames_in_flight": len(fr.slots)},
             "all_rays_per_s_M": round((c["rays"] + c["ao_calls"]) * args.steps / elapsed / 1e6, 2),
             "roofline": {
