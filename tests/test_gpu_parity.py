@@ -349,3 +349,22 @@ def test_tables_beyond_4_gib(native, oracle_mod):
     ok = np.repeat(mask == 0, 4)
     assert np.array_equal(px.view(np.uint32)[ok], want.view(np.uint32)[ok])
     assert ok.mean() > 0.9 and len(np.unique(px)) > 100
+
+
+def test_randomised_parity_smoke():
+    """A short run of tools/fuzz_parity.py (random cameras, presets, volumes, record overrides);
+    the long runs are recorded in profiles/r01_fuzz_parity.txt."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import sys
+
+    argv, sys.argv = sys.argv, ["fuzz_parity.py", "--cases", "40", "--seed", "99"]
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised parity: small frames with random cameras, presets, volumes and record overrides,
+GPU (rm_render_frame through the C ABI) against the CPU restatement, bit for bit.
+
+    python tools/fuzz_parity.py [--cases 200] [--seed 1]
+
+Prints every mismatching case with the parameters that reproduce it; exit code 1 if any.
+(The oracle is used here exactly as the tests use it: as the checker.)"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import oracle
+    import raymarchcl_amd as rm
+    import scenes
+    from raymarchcl_amd import _native, generators as gen, materials, structs
+
+    rng = np.random.default_rng(args.seed)
+    vols = [("gyroid", 64), ("terrain", 64), ("blobs", 64), ("gyroid-crop", (64, 40, 48)), ("gyroid", 32)]
+    sparse = gen.make_blob_volume(64, radius=(0.01, 0.03))
+    mats = sorted(materials.presets)
+    bad = 0
+    ctx = _native.Context(0)
+    for case in range(args.cases):
+        kind, vres = vols[int(rng.integers(len(vols)))]
+        vox = sparse if (kind == "blobs" and rng.random() < 0.5) else scenes.volume(kind, vres)
+        vres3 = [vres] * 3 if isinstance(vres, int) else list(vres)
+        w, h, it = int(rng.integers(17, 64)), int(rng.integers(9, 48)), int(rng.choice([1, 2, 4]))
+        inside = rng.random() < 0.25
+        eye = (rng.uniform(-0.9, 0.9, 3) if inside else
+               rm.compute_eyepos(rng.uniform(0, 360), rng.uniform(1.2, 3.5), rng.uniform(-0.9, 1.6)))
+        base = dict(width=w, height=h, vres=vres3, iter=it, eyepos=[float(v) for v in eye],
+                    targetpos=[float(v) for v in rng.uniform(-0.5, 0.5, 3)], mat=str(rng.choice(mats)),
+                    fov=float(rng.uniform(40, 120)), dof=float(rng.choice([0.0, 0.001, 0.025, 0.1])))
+        over = {}
+        if rng.random() < 0.5:
+            pool = dict(aoIter=int(rng.integers(0, 9)), aoStepDist=float(rng.uniform(0.01, 0.3)),
+                        aoAmp=float(rng.uniform(0.0, 0.6)), voxelSize=float(rng.uniform(0.001, 0.05)),
+                        groundY=float(rng.uniform(0.3, 1.5)), maxVoxelIter=int(rng.integers(8, 300)),
+                        lightScatter=float(rng.uniform(0.0, 0.5)), shadowBias=float(rng.uniform(0.01, 0.3)),
+                        eps=float(rng.uniform(0.001, 0.03)), maxDist=float(rng.uniform(3, 40)),
+                        maxIter=int(rng.integers(4, 160)), shadowIter=int(rng.integers(2, 160)),
+                        reflectIter=int(rng.integers(0, 4)), isoVal=int(rng.integers(0, 200)),
+                        fogPow=float(rng.uniform(0, 0.2)), numLights=int(rng.integers(1, 3)))
+            for k in rng.choice(sorted(pool), size=int(rng.integers(1, 5)), replace=False):
+                over[str(k)] = pool[str(k)]
+        recs = []
+        for i in range(it):
+            o = rm.render_options(t=i * 0.333, **base)
+            o.update(over)
+            recs.append(structs.encode_bytes(o))
+        opts = b"".join(recs)
+        seed = int(rng.integers(1 << 30))
+        mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=seed + i) for i in range(it)])
+        n = w * h - int(rng.integers(0, 5))
+        want = np.zeros(4 * n, np.float32)
+        mask = np.zeros(n, np.uint8)
+        for i in range(it):
+            oracle.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], want, n=n, undefined_mask=mask)
+        ctx.set_volume(vox, vres3)
+        px, _ = ctx.render_frame(opts, mc, n)
+        ok = np.repeat(mask == 0, 4)
+        a, b = px.view(np.uint32)[ok], want.view(np.uint32)[ok]
+        nan = np.isnan(want[ok])
+        diff = int((a[~nan] != b[~nan]).sum()) + int((~np.isnan(px[ok][nan])).sum())
+        if diff:
+            bad += 1
+            print(f"MISMATCH case {case}: {diff} floats; volume {kind} {vres}, base {base}, over {over}, mc seed {seed}, n {n}",
+                  flush=True)
+    ctx.close()
+    print(f"{args.cases} cases, {bad} mismatching")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
