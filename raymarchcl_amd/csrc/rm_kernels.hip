@@ -25,7 +25,7 @@
 // debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
 // over all lanes: samples, outer marches, their turns, filtered turns, voxel walks,
 // dist8 fetches, samples advanced, AO loops.  rmk::dump_work_stats() prints and resets.
-__device__ unsigned long long g_work_stats[48];
+__device__ unsigned long long g_work_stats[64];
 #endif
 
 #ifndef RM_WAVE_SHARE
@@ -171,6 +171,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kern
 #ifdef RM_WORK_STATS
   {
     atomicAdd(&g_work_stats[43], (unsigned long long)tr.ws_redo);
+    for (int k = 0; k < 3; k++) {
+      atomicAdd(&g_work_stats[48 + k], (unsigned long long)tr.ws_k_est[k]);
+      atomicAdd(&g_work_stats[52 + k], (unsigned long long)tr.ws_k_filt[k]);
+    }
     for (int k = 0; k < 4; k++) atomicAdd(&g_work_stats[44 + k], (unsigned long long)tr.ws_k_nohit[k]);
     atomicAdd(&g_work_stats[38], (unsigned long long)(tr.ws_k_one[0] + tr.ws_k_one[1]));
     atomicAdd(&g_work_stats[39], (unsigned long long)tr.ws_k_one[2]);
@@ -472,7 +476,7 @@ int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
 void dump_work_stats() {
 #ifdef RM_WORK_STATS
-  unsigned long long h[48] = {0};
+  unsigned long long h[64] = {0};
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
   const double n = h[0] ? (double)h[0] : 1.0;
@@ -502,10 +506,13 @@ void dump_work_stats() {
   fprintf(stderr, "[work stats] walks without a hit per sample: primary %.2f, reflection %.2f, shadow %.2f, AO %.2f; "
                   "ended by their first fetch: primary+reflection %.2f, shadow %.2f\n",
           h[44] / n, h[45] / n, h[46] / n, h[47] / n, h[38] / n, h[39] / n);
+  fprintf(stderr, "[work stats] turns per sample (estimate + filtered): primary %.2f + %.2f, reflection %.2f + %.2f, "
+                  "shadow %.2f + %.2f\n",
+          h[48] / n, h[52] / n, h[49] / n, h[53] / n, h[50] / n, h[54] / n);
 #endif
 #ifdef RM_PHASE_CLOCK
   {
-    unsigned long long h[48] = {0};
+    unsigned long long h[64] = {0};
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
     const double waves = h[37] ? (double)h[37] : 1.0;
@@ -515,7 +522,7 @@ void dump_work_stats() {
   }
 #endif
 #if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
-  unsigned long long z[48] = {0};
+  unsigned long long z[64] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
 #endif
 }

@@ -248,6 +248,7 @@ struct Tracer {
   unsigned int ws_k_walks[4] = {0, 0, 0, 0}, ws_k_fetch[4] = {0, 0, 0, 0}, ws_k_slots[4] = {0, 0, 0, 0};
   unsigned int ws_dhist[7] = {0, 0, 0, 0, 0, 0, 0};  // fetched dist8 value: 0 (hit), 1, 2, 3, 4-7, 8+; [6] = last value
   unsigned int ws_k_nohit[4] = {0, 0, 0, 0}, ws_k_one[4] = {0, 0, 0, 0};  // walks without a hit; of those, ended by their first fetch
+  unsigned int ws_k_est[4] = {0, 0, 0, 0}, ws_k_filt[4] = {0, 0, 0, 0};  // estimate / filtered turns by march kind
   unsigned int ws_redo = 0;  // marches whose last turn was repeated for its normal
   unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
@@ -678,6 +679,7 @@ struct Tracer {
           RM_WS(wv_filt += wave_slots());
           nw = kFilter && surely_no_walk(flt, dist, g);
           RM_WS(ws_filtered += nw ? 1u : 0u);
+          RM_WS(ws_k_filt[ws_kind] += nw ? 1u : 0u);
           go = nw & !((__builtin_fabsf(g) <= o.eps) | (dist >= maxDist));
           dist = go ? dist + g : dist;
         } while (go & (maxSteps > 0));
@@ -687,6 +689,7 @@ struct Tracer {
       if (why != 1) break;
       float sd;
       RM_WS(wv_est += wave_slots());
+      RM_WS(ws_k_est[ws_kind]++);
       const bool inside = kFilter && surely_inside(flt, dist, g);
       int limit = 0x7fffffff;
       // (`dist` counts in units of |rdir|: the remaining world distance is (maxDist - dist) * |rdir|)
