@@ -132,7 +132,11 @@ def main():
         big = WORKLOADS[args.workload]["vres"] ** 3 > (64 << 20)
         args.frames_in_flight = 1 if big else (3 if world == 1 else 2)
 
-    _native.build()
+    # (no-op when the library is current; several ranks must not rebuild the same file at once)
+    if world == 1 or rank == 0:
+        _native.build()
+    if world > 1:
+        dist.barrier()
     wl = WORKLOADS[args.workload]
     vox, vres, opts, mc = build_inputs(wl)
     n, width, spp = wl["w"] * wl["h"], wl["w"], wl["spp"]
