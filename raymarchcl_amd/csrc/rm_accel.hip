@@ -11,6 +11,9 @@
 //         are in-bounds and empty, so the fixed-step samples that fall into
 //         them neither hit nor leave the grid and need not be fetched
 //         (rm_shade.hpp: exact multi-step advance).
+//  oct8   (8 x 1 B / voxel, behind dist8 in the same buffer)  per sign combination of a walk
+//         direction the edge of the largest empty in-grid cube AHEAD of the cell; same skip
+//         rule with longer skips (see the section further down).
 //  surf32 (4 B / voxel, meaningful where v > isoVal)  everything a hit needs:
 //         bits 0-7 voxel value, 8-13 / 14-19 / 20-25 the x/y/z sums (+32) of the
 //         smooth normal, 26-27 / 28-29 / 30-31 the central differences (+1) of

@@ -154,7 +154,7 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
   if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
   // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
-  // derived structures when ry*rz < 2^24 and rx < 2^24) and an unsigned 32-bit offset
+  // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
 #if RM_BRICKS
   // tables are stored in 8x4x4-cell bricks = one 128-byte line each (rm_accel.hip): lanes
   // of a wavefront and consecutive fetches of a ray then share lines far more often
