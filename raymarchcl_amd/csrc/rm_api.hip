@@ -80,7 +80,7 @@ struct rm_ctx {
   int split_tw = 8, split_lw = 8;  // RAYMARCH_SPLIT_WAVES=t,l
   bool xcd_rows = true;    // RAYMARCH_XCD_ROWS=0: plain block order
   int pass_pack = 4;       // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds
-  int straight_waves = 8;  // RAYMARCH_STRAIGHT_WAVES (3..8): waves/SIMD the register budget of
+  int straight_waves = 7;  // RAYMARCH_STRAIGHT_WAVES (3..8): waves/SIMD the register budget of
                            // render_samples_kernel leaves room for (8 = 64 VGPRs + scratch spills)
   int wave_mode = 0;    // RAYMARCH_KERNEL=wave -> persistent wave-scheduled kernel (experimental)
   int min_waves = 4;    // RAYMARCH_WAVES=2..5: register budget of the wave kernel
