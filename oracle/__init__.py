@@ -112,6 +112,9 @@ def ref_lib(fma=False):
         lib.ref_render_image.argtypes = [_u8p, _f32p, ctypes.c_void_p, _f32p, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int]
         lib.ref_render_image.restype = None
+        lib.ref_render_image_mt.argtypes = [_u8p, _f32p, ctypes.c_void_p, _f32p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.ref_render_image_mt.restype = None
         lib.ref_tonemap_image.argtypes = [_f32p, ctypes.c_void_p, _u32p, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int]
         lib.ref_tonemap_image.restype = None
@@ -194,6 +197,17 @@ def ref_render_image(vox, mc, opts, pixels, n=None, id0=0, id1=None, fma=False):
     ob = ctypes.create_string_buffer(bytes(opts), OPTS_SIZE)
     ref_lib(fma).ref_render_image(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p), n,
                                   id0, id1)
+    return pixels
+
+
+def ref_render_image_mt(vox, mc, opts, pixels, threads, n=None, id0=0, id1=None, fma=False):
+    """ref_render_image spread over `threads` host threads (as a CPU OpenCL device would)."""
+    _check(vox, mc, opts, pixels)
+    n = pixels.size // 4 if n is None else n
+    id1 = n if id1 is None else id1
+    ob = ctypes.create_string_buffer(bytes(opts), OPTS_SIZE)
+    ref_lib(fma).ref_render_image_mt(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p), n,
+                                     id0, id1, int(threads))
     return pixels
 
 

@@ -14,6 +14,7 @@
 // Must be compiled with clang++ (ext_vector_type mangling == OpenCL floatN)
 // and -ffp-contract=off.  No <cmath>: the global names exp/pow/sqrt/... are
 // defined here with OpenCL's C++-mangled signatures.
+#include <pthread.h>
 #include <stddef.h>
 #include <stdint.h>
 #include "cl_scalar.h"
@@ -76,6 +77,39 @@ __attribute__((visibility("default"))) void ref_render_image(
     tl_gid = (size_t)id;
     RenderImage(voxels, mc, opts544, pixels, n);
   }
+}
+// The same over `threads` host threads (an OpenCL CPU device spreads an NDRange over its
+// cores): chunks of 256 work-items handed out through an atomic counter.  pthreads, not
+// <thread>: no C++ math headers may enter this file.
+struct MtJob {
+  const unsigned char* voxels; const float* mc; const void* opts; float* pixels;
+  int n, id1; int next;
+};
+static void* mt_worker(void* arg) {
+  MtJob* j = (MtJob*)arg;
+  for (;;) {
+    const int lo = __atomic_fetch_add(&j->next, 256, __ATOMIC_RELAXED);
+    if (lo >= j->id1) break;
+    const int hi = lo + 256 < j->id1 ? lo + 256 : j->id1;
+    for (int id = lo; id < hi; ++id) {
+      tl_gid = (size_t)id;
+      RenderImage(j->voxels, j->mc, j->opts, j->pixels, j->n);
+    }
+  }
+  return 0;
+}
+__attribute__((visibility("default"))) void ref_render_image_mt(
+    const unsigned char* voxels, const float* mc, const void* opts544, float* pixels, int n,
+    int id0, int id1, int threads) {
+  MtJob job = {voxels, mc, opts544, pixels, n, id1, id0};
+  if (threads < 1) threads = 1;
+  if (threads > 512) threads = 512;
+  pthread_t tid[512];
+  int started = 0;
+  for (int t = 0; t < threads - 1; t++)
+    if (pthread_create(&tid[started], 0, mt_worker, &job) == 0) started++;
+  mt_worker(&job);
+  for (int t = 0; t < started; t++) pthread_join(tid[t], 0);
 }
 __attribute__((visibility("default"))) void ref_tonemap_image(const float* pixels,
                                                               const void* opts544,
