@@ -82,6 +82,9 @@ def restate_lib():
         lib.rmo_render_frame.argtypes = [_u8p, ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, _u32p,
                                          ctypes.c_int, ctypes.c_int, ctypes.POINTER(Stats)]
         lib.rmo_render_frame.restype = None
+        lib.rmo_render_frame_ids.argtypes = [_u8p, ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, _u8p]
+        lib.rmo_render_frame_ids.restype = None
         lib.rmo_render_sdf_frame.argtypes = [_f32p, ctypes.c_void_p, _f32p, ctypes.c_int, _f32p, _u32p,
                                              ctypes.c_int, ctypes.c_int]
         lib.rmo_render_sdf_frame.restype = None
@@ -187,6 +190,22 @@ def render_frame(vox, opts_array, mc_array, n, threads=0, stats=None, tonemap=Tr
                                    _ptr(argb, _u32p) if tonemap else None, n, threads,
                                    ctypes.byref(stats) if stats is not None else None)
     return pixels, argb
+
+
+def render_frame_ids(vox, opts_array, mc_array, n, ids, threads=0, undefined_mask=None):
+    """The pipeline for the work-items ``ids`` only (all passes, in order).  -> pixels float32[n*4],
+    zero except at the ids.  Duplicate ids are not allowed."""
+    iters = len(opts_array) // OPTS_SIZE
+    mc_array = np.ascontiguousarray(mc_array, dtype=np.float32).reshape(-1)
+    assert mc_array.size == iters * TABLE_FLOATS
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    assert len(np.unique(ids)) == len(ids)
+    pixels = np.zeros(n * 4, dtype=np.float32)
+    ob = ctypes.create_string_buffer(bytes(opts_array), len(opts_array))
+    restate_lib().rmo_render_frame_ids(_ptr(vox, _u8p), ob, _ptr(mc_array, _f32p), iters, _ptr(pixels, _f32p), n,
+                                       ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(ids), threads,
+                                       _ptr(undefined_mask, _u8p) if undefined_mask is not None else None)
+    return pixels
 
 
 def ref_render_image(vox, mc, opts, pixels, n=None, id0=0, id1=None, fma=False):

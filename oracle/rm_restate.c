@@ -625,6 +625,37 @@ void rmo_render_frame(const uint8_t* vox, const void* opts_array, const float* m
   if (argb) rmo_tonemap_image(pixels, opts_array, argb, n, 0, n);
 }
 
+/* The pipeline restricted to a list of work-items (sampled parity checks at sizes whose
+ * full frame the CPU cannot render in seconds): for every id in ids[0..count) the `iter`
+ * passes are applied in order to pixels[4*id..] (zeroed first); other pixels are untouched.
+ * undefined_mask (nullable, n bytes) as in rmo_render_image_masked. */
+void rmo_render_frame_ids(const uint8_t* vox, const void* opts_array, const float* mc_array, int iter,
+                          float* pixels, int n, const int32_t* ids, int count, int threads,
+                          uint8_t* undefined_mask) {
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#else
+  threads = 1;
+#endif
+#pragma omp parallel num_threads(threads)
+  {
+    for (int i = 0; i < iter; i++) {
+      ctx_t c;
+      ctx_init(&c, vox, mc_array + (size_t)i * 0x4000 * 4, (const uint8_t*)opts_array + (size_t)i * OPTS_SIZE);
+#pragma omp for schedule(dynamic, 16)
+      for (int k = 0; k < count; k++) {
+        const int id = ids[k];
+        if (id < 0 || id >= n) continue;
+        if (i == 0) memset(pixels + 4 * (size_t)id, 0, 16);
+        const uint64_t before = c.st.oob_material;
+        render_one(&c, pixels, id);
+        if (undefined_mask && c.st.oob_material != before) undefined_mask[id] = 1;
+      }
+      /* (implicit barrier of the omp for: pass i+1 of an id starts after its pass i) */
+    }
+  }
+}
+
 /* QUALITY MODE frame: the pipeline above over a float distance field (rx*ry*rz floats, x
  * fastest, voxelRes of the records) instead of the byte grid.  Not reference-equivalent. */
 void rmo_render_sdf_frame(const float* sdf, const void* opts_array, const float* mc_array, int iter,
