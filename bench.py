@@ -224,7 +224,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "render_samples_kernel<accel, %s waves/SIMD>" % os.environ.get("RAYMARCH_STRAIGHT_WAVES", "7"), "kernel_ms": round(pass_ms, 4),
+                "kernel": "render_frame_kernel<accel, %s waves/SIMD>" % os.environ.get("RAYMARCH_WAVES_PER_SIMD", "7"), "kernel_ms": round(pass_ms, 4),
                 "launches_per_frame": launches,
                 "alg_bytes_per_launch": int(alg_bytes_launch),
                 "alg_bytes_per_sample": round(alg_bytes_frame / samples_per_frame, 1),

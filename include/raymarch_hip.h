@@ -61,6 +61,16 @@ int rm_device_count(void);
 /* cl/select-platform + max-device + make-context + init-state with the
  * compiled program (core.clj:121-128).  device_id: HIP ordinal. */
 int rm_create(int device_id, rm_ctx** out);
+/* The same for a frame spread over several devices of one node (not a reference feature:
+ * the reference drives one device, core.clj:122).  The returned context is used like any
+ * other; rm_set_volume* and the volume producers replicate the volume on every device,
+ * rm_render_frame renders image tiles r, r+N, ... on device_ids[r] and collects the tile
+ * accumulators on device_ids[0] with peer copies over xGMI before it un-permutes and tonemaps
+ * there.  Every other entry point (single passes, the device-resident calls, the quality
+ * mode) runs on device_ids[0] alone.  Ids may repeat (several ranks on one device: a
+ * rehearsal of the partition logic on a single-GPU machine). */
+int rm_create_multi(const int* device_ids, int n_devices, rm_ctx** out);
+int rm_num_devices(rm_ctx* ctx);
 void rm_destroy(rm_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
  * the context's own non-blocking stream.  NULL is a valid handle: the legacy
@@ -79,6 +89,17 @@ int rm_set_volume(rm_ctx* ctx, const uint8_t* voxels, int rx, int ry, int rz);
 /* Same, but the bytes already live in device memory owned by the caller
  * (borrowed until the next rm_set_volume* / rm_destroy). */
 int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int rz);
+/* The tables the kernels derive from the volume (csrc/rm_accel.hip) are cached per
+ * (volume, isoVal).  After modifying a borrowed device volume IN PLACE (the reference's
+ * heat-map animation rewrites its v-buf every frame) call this before the next frame:
+ * the tables are rebuilt and records accepted by rm_check_device_opts must be checked again. */
+int rm_invalidate_volume(rm_ctx* ctx);
+/* Let `dst` use the resident volume of `src` (same device) AND the tables derived from it,
+ * instead of holding its own: contexts that render the same scene on different streams
+ * (frames in flight) then share one set of tables in HBM and in the caches.  The contexts
+ * must not render with different isoVal at the same time; either one detaches by setting
+ * a volume of its own. */
+int rm_share_volume(rm_ctx* dst, rm_ctx* src);
 
 /* gen/make-gyroid-volume (generators.clj:27-42) evaluated on the device: fills the
  * context's resident volume (as rm_set_volume would) and, if voxels_out is not
@@ -150,13 +171,19 @@ int rm_render_sdf_frame(rm_ctx* ctx, const void* opts544_array, const float* mc_
  * 64 float4 each, local tile j at d_tiles[j*64 .. j*64+63] (lane = (y&7)*8 +
  * (x&7)); this is the buffer ranks exchange.
  *
- * rm_frame_device: zero the partition's accumulators, then `iter` RenderImage
- * passes in order with (opts_i, mc_i) over the partition's tiles.
+ * rm_frame_device: the partition's accumulators start from zero, then `iter` RenderImage
+ * passes in order with (opts_i, mc_i) over the partition's tiles.  All records of a frame
+ * must have the same resolution.x.
  * d_opts: iter*544 bytes, d_mc: iter tables, width: image width in pixels.
  * Asynchronous on the context's stream. */
 int rm_tiles_per_part(int resx, int n, int parts);
 int rm_frame_device(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
                     int width, int tile_first, int tile_stride, float* d_tiles);
+/* The unpartitioned frame in ONE kernel launch: all passes, blended in order, the row-major
+ * float4 image into d_pixels (nullable) and TonemapImage(d_opts[0]) into d_argb (nullable;
+ * at least one of the two).  Same validation contract as rm_frame_device. */
+int rm_frame_device_full(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
+                         int width, float* d_pixels, uint32_t* d_argb);
 /* Un-permute `parts` partitions' accumulators (d_tiles_all = partition 0's
  * buffer, then partition 1's, ... each rm_tiles_per_part()*64 float4) into the
  * row-major float4 image d_pixels (nullable) and run TonemapImage with
@@ -168,10 +195,11 @@ int rm_resolve_device(rm_ctx* ctx, const float* d_tiles_all, int parts, const vo
  * TRenderOpts.resolution.x.  This synchronous helper fetches the `iter` records
  * once and applies the same validation the host-buffer entry points do
  * (resolution, voxelRes against the resident volume, numLights), and notes each
- * record's isoVal; rm_frame_device refuses d_opts that were not checked.  It also
+ * record's isoVal; rm_frame_device[_full] refuse d_opts that were not checked, or were
+ * checked with another iter / n / width or against another resident volume.  It also
  * builds the structures derived from the volume for the first record's isoVal
  * (otherwise the first frame would).  Call it again after rewriting the records
- * in place. */
+ * in place, and after rm_set_volume* / rm_invalidate_volume. */
 int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int width);
 
 /* Elapsed milliseconds of the RenderImage-pass kernels of the last
@@ -179,6 +207,9 @@ int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int w
  * one), measured with HIP events on the stream they ran on (synchronises).
  * launches = number of render kernel launches in that interval. */
 int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
+/* Device time (HIP events) of the last build of the tables derived from the resident volume
+ * (dist8 + oct8 + surf32; once per (volume, isoVal), inside the first call that needs them). */
+int rm_last_table_build_ms(rm_ctx* ctx, float* ms);
 
 /* Test hook: copy out the derived structures the kernels use for the resident
  * volume at hit threshold `iso` (see csrc/rm_accel.hip): dist_out = rx*ry*rz

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 # RAYMARCH_LIB: load (and build) another file of this directory instead, e.g. an A/B
 # variant built with extra flags by tools/ab_build.py; the product default is the name below
 LIB_PATH = os.path.join(HERE, os.path.basename(os.environ.get("RAYMARCH_LIB", "libraymarch_hip.so")))
-SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_volgen.hip", "rm_stream.hip", "rm_api.hip", "rm_host.cpp"]
+SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_volgen.hip", "rm_api.hip", "rm_host.cpp"]
 # -fno-slp-vectorize: packed f32 VALU (v_pk_add_f32 ...) buys nothing on this chip and its
 # even-aligned register pairs cost moves and spills in a 64-VGPR kernel (measured -5 % frame time)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -26,8 +26,9 @@ TABLE_FLOATS = 0x4000 * 4
 
 # every symbol include/raymarch_hip.h declares
 EXPORTS = [
-    "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_destroy",
-    "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_create_multi", "rm_num_devices",
+    "rm_destroy", "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_invalidate_volume", "rm_share_volume", "rm_frame_device_full", "rm_last_table_build_ms",
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
@@ -108,6 +109,12 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.rm_last_error.restype = ctypes.c_char_p
     L.rm_create.argtypes = [_i, ctypes.POINTER(_vp)]
+    L.rm_create_multi.argtypes = [ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)]
+    L.rm_num_devices.argtypes = [_vp]
+    L.rm_invalidate_volume.argtypes = [_vp]
+    L.rm_share_volume.argtypes = [_vp, _vp]
+    L.rm_frame_device_full.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]
+    L.rm_last_table_build_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_float)]
     L.rm_destroy.argtypes = [_vp]
     L.rm_destroy.restype = None
     L.rm_set_stream.argtypes = [_vp, _vp]
@@ -152,10 +159,20 @@ class Context:
     """Owns one rm_ctx (one device, one stream)."""
 
     def __init__(self, device_id=0):
+        """device_id: a HIP ordinal, or a sequence of ordinals for one frame spread over several
+        devices (rm_create_multi; ordinals may repeat)."""
         self._h = _vp()
-        check(lib().rm_create(device_id, ctypes.byref(self._h)))
+        if isinstance(device_id, (list, tuple)):
+            ids = (_i * len(device_id))(*[int(d) for d in device_id])
+            check(lib().rm_create_multi(ids, len(device_id), ctypes.byref(self._h)))
+        else:
+            check(lib().rm_create(int(device_id), ctypes.byref(self._h)))
         self.device_id = device_id
         self.vres = None
+
+    @property
+    def num_devices(self):
+        return int(lib().rm_num_devices(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -187,6 +204,15 @@ class Context:
         rx, ry, rz = (int(v) for v in vres)
         check(lib().rm_set_volume_device(self._h, dptr, rx, ry, rz))
         self.vres = (rx, ry, rz)
+
+    def share_volume(self, src):
+        """Use ``src``'s resident volume and the tables derived from it (same device)."""
+        check(lib().rm_share_volume(self._h, src._h))
+        self.vres = src.vres
+
+    def invalidate_volume(self):
+        """After an in-place edit of a borrowed device volume: derived tables are rebuilt."""
+        check(lib().rm_invalidate_volume(self._h))
 
     def make_gyroid_volume(self, vres, want_host_copy=True):
         """Generate the gyroid benchmark volume on the device; it becomes the resident
@@ -307,6 +333,15 @@ class Context:
         accumulators (device pointers as ints); asynchronous."""
         check(lib().rm_frame_device(self._h, d_opts, d_mc, iters, n, width, tile_first, tile_stride,
                                     d_tiles))
+
+    def frame_device_full(self, d_opts, d_mc, iters, n, width, d_pixels=None, d_argb=None):
+        """The unpartitioned frame in one launch: row-major pixels and / or ARGB; asynchronous."""
+        check(lib().rm_frame_device_full(self._h, d_opts, d_mc, iters, n, width, d_pixels, d_argb))
+
+    def last_table_build_ms(self):
+        ms = ctypes.c_float()
+        check(lib().rm_last_table_build_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)
 
     def resolve_device(self, d_tiles_all, parts, d_opts, n, width, d_pixels=None, d_argb=None):
         check(lib().rm_resolve_device(self._h, d_tiles_all, parts, d_opts, n, width, d_pixels, d_argb))

@@ -193,25 +193,6 @@ __global__ __launch_bounds__(256) void oct_kernel(const uint32_t* __restrict__ s
   }
 }
 
-// row-major table <-> 8x4x4-cell bricks (128 B each, x fastest inside and between bricks);
-// cells of partial bricks beyond the grid hold 0
-__global__ __launch_bounds__(256) void brick_kernel(const uint8_t* __restrict__ lin, Dim d,
-                                                    uint8_t* __restrict__ bricked, int to_bricks) {
-  const int nbx = (d.rx + 7) >> 3, nby = (d.ry + 3) >> 2, nbz = (d.rz + 3) >> 2;
-  const long long total = (long long)nbx * nby * nbz * 128;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long b = i >> 7;
-    const int w = (int)(i & 127);
-    const int x = (int)(b % nbx) * 8 + (w & 7), y = (int)((b / nbx) % nby) * 4 + ((w >> 3) & 3),
-              z = (int)(b / ((long long)nbx * nby)) * 4 + (w >> 5);
-    const bool in = x < d.rx && y < d.ry && z < d.rz;
-    const long long l = ((long long)z * d.ry + y) * d.rx + x;
-    if (to_bricks) bricked[i] = in ? lin[l] : 0;
-    else if (in) const_cast<uint8_t*>(lin)[l] = bricked[i];
-  }
-}
-
 // The benchmark volume on the device (reference generators.clj:18-42 fills it on one
 // JVM thread, minutes for 512^3).  Same formula in binary64; cos/sin come from the
 // device math library, so a voxel whose value sits within an ulp of a threshold may
@@ -246,16 +227,7 @@ hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz)
   return hipGetLastError();
 }
 
-long long bricked_bytes(int rx, int ry, int rz) {
-  return (long long)((rx + 7) >> 3) * ((ry + 3) >> 2) * ((rz + 3) >> 2) * 128;
-}
-hipError_t launch_brick(hipStream_t st, uint8_t* d_lin, int rx, int ry, int rz, uint8_t* d_bricked,
-                        bool to_bricks) {
-  const long long total = bricked_bytes(rx, ry, rz);
-  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  brick_kernel<<<blocks, 256, 0, st>>>(d_lin, Dim{rx, ry, rz}, d_bricked, to_bricks ? 1 : 0);
-  return hipGetLastError();
-}
+size_t octant_scratch_bytes(int rx, int ry, int rz) { return (size_t)(rx + 1) * (ry + 1) * (rz + 1) * 4; }
 
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                          uint8_t* d_dist9, uint32_t* d_sat) {

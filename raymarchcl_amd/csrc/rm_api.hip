@@ -10,13 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/raymarch_hip.h"
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
-#include "rm_stream.h"
 
 static_assert(sizeof(rm_counters) == sizeof(rmk::Counters), "counter structs must match");
 static_assert(RM_OPTS_BYTES == RM_OPTS_SIZE, "option record size");
@@ -60,43 +61,51 @@ struct DevBuf {
   }
 };
 
+// The resident byte volume and everything derived from it (rm_accel.hip).  Contexts of one
+// device may share it (rm_share_volume): frames in flight on several streams then read ONE
+// set of tables -- 208 MiB at 256^3 -- instead of one per context.
+struct Volume {
+  std::mutex mu;
+  int device = 0;
+  const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
+  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf, sat_buf;
+  int rx = 0, ry = 0, rz = 0;
+  int accel_iso = -1;              // isoVal the tables were built for, -1 = stale
+  unsigned long long oct_stride = 0;
+  unsigned long long generation = 0;  // bumped whenever the bytes (may) have changed
+  double accel_build_ms = 0.0;     // wall time of the last table build (reported by bench.py)
+  ~Volume() {
+    (void)hipSetDevice(device);
+    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release(); sat_buf.release();
+  }
+};
+
 }  // namespace
 
 struct rm_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
-  DevBuf vox_buf, mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o;
-  DevBuf dist_buf, tmp_buf, surf_buf, stage_buf, queue_buf, work_buf, gen_buf, sat_buf, lin_buf, sdf_buf;
+  std::shared_ptr<Volume> vol;
+  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
-  bool sdf_frame = false;                  // frame_on_device renders the distance field
-  bool use_octants = false;
-  unsigned long long oct_stride = 0;
-  int stream_mode = 0;                 // RAYMARCH_KERNEL=straight (default) | stream | wave
-  long long batch_samples = 8 << 20;   // RAYMARCH_BATCH_SAMPLES: samples per stream batch
-  int phase_mode = 0;      // RAYMARCH_KERNEL=phases: chain / point rays / shading as three launches
-  int split_mode = 0;      // RAYMARCH_KERNEL=split: march chain and lighting as two launches
-  int split_tw = 8, split_lw = 8;  // RAYMARCH_SPLIT_WAVES=t,l
-  bool xcd_rows = true;    // RAYMARCH_XCD_ROWS=0: plain block order
-  int pass_pack = 4;       // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds
-  int straight_waves = 7;  // RAYMARCH_STRAIGHT_WAVES (3..8): waves/SIMD the register budget of
-                           // render_samples_kernel leaves room for (8 = 64 VGPRs + scratch spills)
-  int wave_mode = 0;    // RAYMARCH_KERNEL=wave -> persistent wave-scheduled kernel (experimental)
-  int min_waves = 4;    // RAYMARCH_WAVES=2..5: register budget of the wave kernel
-  int wave_blocks = 0;  // persistent grid size
-  int wait_lanes = 16;  // RAYMARCH_WAIT_LANES: continuation/march vote weight in 1/16 (16 = plain majority)
-  int num_cus = 0;  // rm_accel.hip structures of the resident volume
-  int accel_iso = -1;                  // isoVal they were built for, -1 = stale
-  bool use_accel = true;               // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
-  std::vector<int> dev_iso;            // isoVal per record, noted by rm_check_device_opts
-  std::vector<unsigned char> dev_same; // record i == record i-1 except .time
-  std::vector<RmOpts> dev_recs;        // host copy of the checked records
-  const void* dev_iso_src = nullptr;
-  int rx = 0, ry = 0, rz = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
+  bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
+  int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most
+  int waves_per_simd = 7;    // RAYMARCH_WAVES_PER_SIMD (4..8): register budget of the frame kernel
+  bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
+  // records validated by rm_check_device_opts
+  std::vector<RmOpts> dev_recs;
+  std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
+  const void* dev_src = nullptr;
+  int dev_iter = 0, dev_n = 0, dev_width = 0;
+  unsigned long long dev_generation = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
   bool timed = false;
   int launches = 0;
+  // rm_create_multi: the other devices of a multi-device context (this one is rank 0)
+  std::vector<rm_ctx*> peers;
+  rm_ctx* parent = nullptr;
 };
 
 namespace {
@@ -108,66 +117,80 @@ int check_ctx(rm_ctx* c) {
   return RM_OK;
 }
 
+bool have_volume(rm_ctx* c) { return c->vol && c->vol->d_vox; }
+
 // The record's own fields must be usable before a kernel trusts them.
 int check_opts(rm_ctx* c, const void* opts544, int n) {
   RmOpts o;
   memcpy(&o, opts544, sizeof o);
+  const Volume& v = *c->vol;
   if (o.resolution[0] <= 0 || o.resolution[1] <= 0)
     return fail(RM_EINVAL, "TRenderOpts.resolution = (%d,%d)", o.resolution[0], o.resolution[1]);
-  if (o.voxelRes[0] != c->rx || o.voxelRes[1] != c->ry || o.voxelRes[2] != c->rz ||
-      o.voxelRes[3] != c->rx * c->ry)
+  if (o.voxelRes[0] != v.rx || o.voxelRes[1] != v.ry || o.voxelRes[2] != v.rz ||
+      o.voxelRes[3] != v.rx * v.ry)
     return fail(RM_EINVAL, "TRenderOpts.voxelRes = (%d,%d,%d,%d) does not match the volume %dx%dx%d",
-                o.voxelRes[0], o.voxelRes[1], o.voxelRes[2], o.voxelRes[3], c->rx, c->ry, c->rz);
+                o.voxelRes[0], o.voxelRes[1], o.voxelRes[2], o.voxelRes[3], v.rx, v.ry, v.rz);
   if (o.numLights > 4) return fail(RM_EINVAL, "TRenderOpts.numLights = %d (max 4)", (int)o.numLights);
   if (n < 0) return fail(RM_EINVAL, "n = %d", n);
   return RM_OK;
 }
+// all records of a frame: each valid, all with record 0's image width (the accumulator layout,
+// the tile geometry and the work-item -> pixel map are one per frame)
+int check_frame_opts(rm_ctx* c, const RmOpts* recs, int iter, int n, int width) {
+  for (int i = 0; i < iter; i++) {
+    int rc = check_opts(c, &recs[i], n);
+    if (rc) return rc;
+    if (recs[i].resolution[0] != width)
+      return fail(RM_EINVAL, "record %d: resolution.x = %d but the frame is %d wide", i, recs[i].resolution[0], width);
+  }
+  return RM_OK;
+}
 
-// Build (or reuse) dist8/surf32 for the hit threshold of this launch.
+// Build (or reuse) dist8 / oct8 / surf32 for the hit threshold of this launch.
 int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   *out = rmk::Accel{};
   if (!c->use_accel) return RM_OK;
+  Volume& v = *c->vol;
   // walk_step indexes with 24-bit multiplies: fall back to the plain march otherwise
-  if ((long long)c->ry * c->rz >= (1 << 24) || c->rx >= (1 << 24)) return RM_OK;
-  const size_t vox = (size_t)c->rx * c->ry * c->rz;
-  if (c->accel_iso != iso) {
+  if ((long long)v.ry * v.rz >= (1 << 24) || v.rx >= (1 << 24)) return RM_OK;
+  const size_t vox = (size_t)v.rx * v.ry * v.rz;
+  std::lock_guard<std::mutex> lock(v.mu);
+  if (v.accel_iso != iso) {
     // directional tables behind dist8 (measured -10 % frame time at 256^3, -12 % at 512^3 with
     // 8 % fill); table offsets are 64-bit, nine 1024^3 tables span 9 GiB
     const bool oct = c->use_octants;
     const int tables = oct ? 9 : 1;
-#if RM_BRICKS
-    // tables are built row-major in lin_buf, then re-laid in 8x4x4 bricks
-    const size_t bb = (size_t)rmk::bricked_bytes(c->rx, c->ry, c->rz);
-    HIP_TRY(c->lin_buf.reserve(vox * tables));
-    HIP_TRY(c->dist_buf.reserve(bb * tables));
-    uint8_t* lin = static_cast<uint8_t*>(c->lin_buf.p);
-#else
-    HIP_TRY(c->dist_buf.reserve(vox * tables));
-    uint8_t* lin = static_cast<uint8_t*>(c->dist_buf.p);
-#endif
-    HIP_TRY(c->tmp_buf.reserve(vox));
-    HIP_TRY(c->surf_buf.reserve(vox * 4));
-    HIP_TRY(rmk::build_accel(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso, lin,
-                             static_cast<uint8_t*>(c->tmp_buf.p), static_cast<uint32_t*>(c->surf_buf.p)));
-    c->oct_stride = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(v.dist_buf.reserve(vox * tables));
+    uint8_t* lin = static_cast<uint8_t*>(v.dist_buf.p);
+    HIP_TRY(v.tmp_buf.reserve(vox));
+    HIP_TRY(v.surf_buf.reserve(vox * 4));
+    HIP_TRY(hipEventRecord(t0, c->stream));
+    HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
+                             static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
+    v.oct_stride = 0;
     if (oct) {
-      const size_t sat = (size_t)(c->rx + 1) * (c->ry + 1) * (c->rz + 1) * 4;
-      HIP_TRY(c->sat_buf.reserve(sat));
-      HIP_TRY(rmk::build_octants(c->stream, c->d_vox, c->rx, c->ry, c->rz, iso, lin,
-                                 static_cast<uint32_t*>(c->sat_buf.p)));
-      c->oct_stride = vox;
+      HIP_TRY(v.sat_buf.reserve(rmk::octant_scratch_bytes(v.rx, v.ry, v.rz)));
+      HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
+                                 static_cast<uint32_t*>(v.sat_buf.p)));
+      v.oct_stride = vox;
     }
-#if RM_BRICKS
-    for (int t = 0; t < tables; t++)
-      HIP_TRY(rmk::launch_brick(c->stream, lin + (size_t)t * vox, c->rx, c->ry, c->rz,
-                                static_cast<uint8_t*>(c->dist_buf.p) + (size_t)t * bb, true));
-    if (oct) c->oct_stride = bb;
-#endif
-    c->accel_iso = iso;
+    HIP_TRY(hipEventRecord(t1, c->stream));
+    // contexts that share the volume run on other streams: the tables are complete before
+    // anybody else can see accel_iso
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    v.accel_build_ms = ms;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    v.accel_iso = iso;
   }
-  out->oct_stride = c->oct_stride;
-  out->dist = static_cast<const uint8_t*>(c->dist_buf.p);
-  out->surf = static_cast<const uint32_t*>(c->surf_buf.p);
+  out->oct_stride = v.oct_stride;
+  out->dist = static_cast<const uint8_t*>(v.dist_buf.p);
+  out->surf = static_cast<const uint32_t*>(v.surf_buf.p);
   return RM_OK;
 }
 
@@ -188,7 +211,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!mc || !opts544 || (!pixels && n > 0)) return fail(RM_EINVAL, "NULL buffer");
-  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
   rc = check_opts(c, opts544, n);
   if (rc) return rc;
   if (n == 0) return RM_OK;
@@ -210,7 +233,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   rmk::Accel accel;
   rc = ensure_accel(c, o.isoVal, &accel);
   if (rc) return rc;
-  HIP_TRY(rmk::launch_render_pass(c->stream, c->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
+  HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
                                   static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -226,117 +249,71 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   return RM_OK;
 }
 
-// Records i0..i1-1 may share a wave-kernel launch when they are byte-identical
-// apart from .time (what core.clj:99-106 produces).  `uniform[i]` is filled by
-// the callers that have host copies of the records (1 = same as record i-1).
+// What a frame writes: tile-major accumulators of a partition (the multi-GPU exchange unit),
+// or -- unpartitioned -- the row-major float4 image and, with the last pass, the ARGB image.
+struct FrameOut {
+  float* acc = nullptr;
+  uint32_t* argb = nullptr;
+  bool row_major = false;
+  int tile_first = 0, tile_stride = 1;
+};
+
+// The pipeline of core.clj:76-97 on resident inputs: accumulator from zero, `iter` passes in
+// order.  Consecutive passes whose records are identical apart from .time (what
+// core.clj:99-106 produces) and share a hit threshold go out as ONE launch of the frame
+// kernel, pass-packed; a record that differs otherwise starts a new launch, which continues
+// from the accumulator the previous one left (launches of a stream are ordered).
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
-                    int tile_first, int tile_stride, float* d_tiles, const int* iso_per_pass,
-                    const unsigned char* same_as_prev, const RmOpts* host_recs) {
-  const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), tile_stride);
-  const long long count = (long long)tpp * 64;
-  // passes that share a hit threshold share the derived structures and go out as
-  // one launch (the reference's pipeline always has one isoVal: core.clj:49)
-  HIP_TRY(c->stage_buf.reserve((size_t)iter * count * 16));
-  float* staging = static_cast<float*>(c->stage_buf.p);
+                    const FrameOut& out, const unsigned char* same_as_prev, const RmOpts* host_recs,
+                    bool sdf_frame) {
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int launches = 0;
   for (int i0 = 0; i0 < iter;) {
     int i1 = i0 + 1;
-    const bool wave = c->wave_mode && c->use_accel;
-    const bool need_same = wave || c->pass_pack > 0 || c->phase_mode;  // launches whose lanes share one record
-    while (i1 < iter && iso_per_pass[i1] == iso_per_pass[i0] && (!need_same || same_as_prev[i1])) i1++;
-    if (c->sdf_frame) {  // quality mode: no derived structures
-      HIP_TRY(rmk::launch_render_sdf(c->stream, static_cast<const float*>(c->sdf_buf.p),
-                                     d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx, i1 - i0,
-                                     staging + (size_t)i0 * count * 4, n, tile_first, tile_stride,
-                                     c->pass_pack));
-      launches++;
-      i0 = i1;
-      continue;
-    }
-    rmk::Accel accel;
-    int rc = ensure_accel(c, iso_per_pass[i0], &accel);
-    if (rc) return rc;
-    const RmOpts& h0 = host_recs[i0];
-    const bool stream = c->stream_mode && c->use_accel && h0.aoIter >= 0 &&
-                        h0.aoIter <= rmk::kStreamMaxAoIter && h0.reflectIter <= rmk::kStreamMaxReflect;
-    if (stream) {
-      // split the run further so that records differ only in .time, then into batches
-      int j0 = i0;
-      while (j0 < i1) {
-        int j1 = j0 + 1;
-        while (j1 < i1 && same_as_prev[j1]) j1++;
-        const int levels = 1 + (host_recs[j0].reflectIter > 0 ? host_recs[j0].reflectIter : 0);
-        const int nl = host_recs[j0].numLights;
-        long long per = c->batch_samples / count;
-        if (per < 1) per = 1;
-        for (int b0 = j0; b0 < j1;) {
-          int b1 = (int)((long long)b0 + per < j1 ? b0 + per : j1);
-          while ((long long)(b1 - b0) * count > rmk::kStreamMaxSamples && b1 > b0 + 1) b1--;
-          rmk::StreamLaunch sl;
-          sl.vox = c->d_vox;
-          sl.accel = accel;
-          sl.mc = d_mc + (size_t)b0 * RM_TABLE_FLOATS;
-          sl.opts = d_opts + b0;
-          sl.staging = staging + (size_t)b0 * count * 4;
-          sl.n = n; sl.resx = resx; sl.passes = b1 - b0; sl.count = (int)count;
-          sl.tile_first = tile_first; sl.tile_stride = tile_stride;
-          sl.levels = levels; sl.num_lights = nl < 1 ? 1 : nl;
-          sl.queue_blocks = c->num_cus * 8;
-          HIP_TRY(c->work_buf.reserve(rmk::stream_workspace_bytes(sl.passes * sl.count, levels, sl.num_lights)));
-          sl.workspace = c->work_buf.p;
-          HIP_TRY(rmk::launch_stream_batch(c->stream, sl));
-          launches++;
-          b0 = b1;
-        }
-        j0 = j1;
-      }
-      i0 = i1;
-      continue;
-    }
-    if (c->phase_mode && c->use_accel) {
-      const int levels = 1 + (h0.reflectIter > 0 ? h0.reflectIter : 0);
-      HIP_TRY(c->work_buf.reserve(rmk::phases_workspace_bytes((size_t)(i1 - i0) * count, levels)));
-      HIP_TRY(rmk::launch_render_phases(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
-                                        d_opts + i0, resx, i1 - i0, levels,
-                                        staging + (size_t)i0 * count * 4, c->work_buf.p, n, tile_first,
-                                        tile_stride, c->pass_pack));
-      launches++;
-      i0 = i1;
-      continue;
-    }
-    if (c->split_mode && c->use_accel) {
-      const int levels = 1 + (h0.reflectIter > 0 ? h0.reflectIter : 0);
-      HIP_TRY(c->work_buf.reserve((size_t)levels * (i1 - i0) * count * 32));
-      HIP_TRY(rmk::launch_render_split(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
-                                       d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4,
-                                       static_cast<float*>(c->work_buf.p), n, tile_first, tile_stride,
-                                       c->split_tw, c->split_lw));
-      launches++;
-      i0 = i1;
-      continue;
-    }
-    if (wave) {
-      HIP_TRY(c->queue_buf.reserve(64));
-      HIP_TRY(rmk::launch_render_wave(c->stream, c->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS,
-                                      d_opts + i0, resx, i1 - i0, staging + (size_t)i0 * count * 4, n,
-                                      tile_first, tile_stride,
-                                      static_cast<unsigned int*>(c->queue_buf.p), c->wave_blocks,
-                                      c->min_waves, c->wait_lanes));
+    while (i1 < iter && same_as_prev[i1]) i1++;
+    rmk::FrameLaunch f;
+    if (sdf_frame) {  // quality mode: no derived structures
+      f.sdf = static_cast<const float*>(c->sdf_buf.p);
     } else {
-      HIP_TRY(rmk::launch_render_samples(c->stream, c->d_vox, accel,
-                                         d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0, resx,
-                                         i1 - i0, staging + (size_t)i0 * count * 4, n, tile_first,
-                                         tile_stride, c->straight_waves, c->pass_pack, c->xcd_rows));
+      int rc = ensure_accel(c, host_recs[i0].isoVal, &f.accel);
+      if (rc) return rc;
+      f.vox = c->vol->d_vox;
     }
+    f.mc_all = d_mc + (size_t)i0 * RM_TABLE_FLOATS;
+    f.opts_all = d_opts + i0;
+    f.opts0 = d_opts;
+    f.acc = out.acc;
+    f.argb = i1 == iter ? out.argb : nullptr;
+    f.resx = resx; f.n = n; f.passes = i1 - i0;
+    f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
+    f.min_waves = c->waves_per_simd;
+    f.pp_log2 = rmk::choose_pass_pack(i1 - i0, c->pass_pack);
+    f.xcd_rows = c->xcd_rows;
+    f.accumulate = i0 > 0;
+    f.row_major = out.row_major;
+    HIP_TRY(rmk::launch_render_frame(c->stream, f));
     launches++;
     i0 = i1;
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
-  HIP_TRY(rmk::launch_blend(c->stream, staging, d_opts, iter, count, d_tiles));
   c->timed = true;
   c->launches = launches;
   return RM_OK;
+}
+
+// fresh, unshared volume state for a context (rm_set_volume* detach from a shared one)
+int new_volume(rm_ctx* c) {
+  Volume* v = new (std::nothrow) Volume();
+  if (!v) return fail(RM_EDEVICE, "out of host memory");
+  v->device = c->device;
+  static unsigned long long next_generation = 1;
+  v->generation = next_generation++;
+  c->vol.reset(v);
+  return RM_OK;
+}
+void bump_generation(Volume& v) {
+  v.accel_iso = -1;
+  v.generation += (1ull << 32);
 }
 
 }  // namespace
@@ -347,7 +324,7 @@ extern "C" {
 int rm_host_fail_(int code, const char* msg) { return fail(code, "%s", msg); }
 
 const char* rm_last_error(void) { return g_err; }
-int rm_abi_version(void) { return 1; }
+int rm_abi_version(void) { return 2; }
 
 int rm_device_count(void) {
   int n = 0;
@@ -358,8 +335,7 @@ int rm_device_count(void) {
   return n;
 }
 
-int rm_create(int device_id, rm_ctx** out) {
-  if (!out) return fail(RM_EINVAL, "out is NULL");
+static int create_one(int device_id, rm_ctx** out) {
   *out = nullptr;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -379,53 +355,90 @@ int rm_create(int device_id, rm_ctx** out) {
   e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     rm_destroy(c);
     return fail(RM_EDEVICE, "stream/event creation: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  if (new_volume(c) != RM_OK) {
+    rm_destroy(c);
+    return RM_EDEVICE;
+  }
+  // A/B switches (defaults are the measured best)
   const char* na = getenv("RAYMARCH_NO_ACCEL");
   c->use_accel = !(na && na[0] == '1');
   const char* oc = getenv("RAYMARCH_OCTANTS");
-  c->use_octants = !(oc && oc[0] == '0');  // directional tables: on unless RAYMARCH_OCTANTS=0
-  const char* km = getenv("RAYMARCH_KERNEL");
-  c->wave_mode = km && strcmp(km, "wave") == 0;  // experimental, slower: see DESIGN.md
-  c->stream_mode = km && strcmp(km, "stream") == 0;  // experimental task-queue pipeline
-  c->split_mode = km && strcmp(km, "split") == 0;
-  c->phase_mode = km && strcmp(km, "phases") == 0;
-  const char* spw = getenv("RAYMARCH_SPLIT_WAVES");
-  if (spw) sscanf(spw, "%d,%d", &c->split_tw, &c->split_lw);
+  c->use_octants = !(oc && oc[0] == '0');
   const char* xr = getenv("RAYMARCH_XCD_ROWS");
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) c->pass_pack = atoi(pk);
-  const char* sw = getenv("RAYMARCH_STRAIGHT_WAVES");
-  if (sw && atoi(sw) >= 3 && atoi(sw) <= 8) c->straight_waves = atoi(sw);
-  const char* bs = getenv("RAYMARCH_BATCH_SAMPLES");
-  if (bs && atoll(bs) > 0) c->batch_samples = atoll(bs);
-  const char* mw = getenv("RAYMARCH_WAVES");
-  if (mw && atoi(mw) >= 2 && atoi(mw) <= 5) c->min_waves = atoi(mw);
-  c->num_cus = prop.multiProcessorCount;
-  c->wave_blocks = c->num_cus * rmk::wave_kernel_blocks_per_cu(c->min_waves);
-  const char* wl = getenv("RAYMARCH_WAIT_LANES");
-  if (wl && atoi(wl) > 0) c->wait_lanes = atoi(wl);
-  const char* wb = getenv("RAYMARCH_WAVE_BLOCKS");
-  if (wb && atoi(wb) > 0) c->wave_blocks = atoi(wb);
+  const char* sw = getenv("RAYMARCH_WAVES_PER_SIMD");
+  if (sw && atoi(sw) >= 4 && atoi(sw) <= 8) c->waves_per_simd = atoi(sw);
   *out = c;
   return RM_OK;
 }
 
+int rm_create(int device_id, rm_ctx** out) {
+  if (!out) return fail(RM_EINVAL, "out is NULL");
+  return create_one(device_id, out);
+}
+
+int rm_create_multi(const int* device_ids, int n_devices, rm_ctx** out) {
+  if (!out) return fail(RM_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64)
+    return fail(RM_EINVAL, "rm_create_multi: %d devices", n_devices);
+  rm_ctx* root = nullptr;
+  int rc = create_one(device_ids[0], &root);
+  if (rc) return rc;
+  for (int r = 1; r < n_devices; r++) {
+    rm_ctx* p = nullptr;
+    rc = create_one(device_ids[r], &p);
+    if (rc) {
+      rm_destroy(root);
+      return rc;
+    }
+    p->parent = root;
+    root->peers.push_back(p);
+    // direct xGMI access between the root and this device (the tile gather is a peer copy);
+    // harmless when unavailable or when both ranks sit on one device: the copy still works
+    if (device_ids[r] != device_ids[0]) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[r]) == hipSuccess && can) {
+        (void)hipSetDevice(device_ids[0]);
+        (void)hipDeviceEnablePeerAccess(device_ids[r], 0);
+        (void)hipSetDevice(device_ids[r]);
+        (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+      }
+      (void)hipGetLastError();
+    }
+  }
+  (void)hipSetDevice(device_ids[0]);
+  *out = root;
+  return RM_OK;
+}
+
+int rm_num_devices(rm_ctx* c) { return c ? 1 + (int)c->peers.size() : 0; }
+
 void rm_destroy(rm_ctx* c) {
   if (!c) return;
+  for (rm_ctx* p : c->peers) {
+    p->parent = nullptr;
+    rm_destroy(p);
+  }
+  c->peers.clear();
   (void)hipSetDevice(c->device);
   rmk::dump_work_stats();
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  DevBuf* bufs[] = {&c->vox_buf, &c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->dist_buf, &c->tmp_buf, &c->surf_buf, &c->stage_buf, &c->queue_buf, &c->work_buf,
-                    &c->cnt_buf, &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sat_buf, &c->lin_buf,
-                    &c->sdf_buf};
+  DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
+                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf};
   for (DevBuf* b : bufs) b->release();
+  c->vol.reset();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -440,6 +453,11 @@ int rm_set_stream(rm_ctx* c, void* hip_stream) {
 int rm_synchronize(rm_ctx* c) {
   int rc = check_ctx(c);
   if (rc) return rc;
+  for (rm_ctx* p : c->peers) {
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }
@@ -452,6 +470,40 @@ static int check_res(int rx, int ry, int rz) {
   return RM_OK;
 }
 
+// A new resident volume invalidates everything that was derived from or validated against
+// the old one: the context gets fresh volume state (it no longer shares anybody's tables)
+// and forgets the device records rm_check_device_opts had accepted.
+static int begin_new_volume(rm_ctx* c, bool keep_buffer) {
+  c->dev_src = nullptr;
+  c->dev_recs.clear();
+  if (keep_buffer && c->vol && c->vol.use_count() == 1) {
+    bump_generation(*c->vol);
+    return RM_OK;
+  }
+  return new_volume(c);
+}
+
+// replicate the root's resident bytes on the other devices of a multi-device context
+static int broadcast_volume(rm_ctx* c) {
+  if (c->peers.empty()) return RM_OK;
+  const Volume& v = *c->vol;
+  const size_t bytes = (size_t)v.rx * v.ry * v.rz;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (rm_ctx* p : c->peers) {
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = begin_new_volume(p, true);
+    if (rc) return rc;
+    Volume& pv = *p->vol;
+    HIP_TRY(pv.vox_buf.reserve(bytes));
+    HIP_TRY(hipMemcpyPeerAsync(pv.vox_buf.p, p->device, v.d_vox, c->device, bytes, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    pv.d_vox = static_cast<const uint8_t*>(pv.vox_buf.p);
+    pv.rx = v.rx; pv.ry = v.ry; pv.rz = v.rz;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  return RM_OK;
+}
+
 int rm_set_volume(rm_ctx* c, const uint8_t* voxels, int rx, int ry, int rz) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -459,13 +511,15 @@ int rm_set_volume(rm_ctx* c, const uint8_t* voxels, int rx, int ry, int rz) {
   rc = check_res(rx, ry, rz);
   if (rc) return rc;
   const size_t bytes = (size_t)rx * ry * rz;
-  HIP_TRY(c->vox_buf.reserve(bytes));
-  HIP_TRY(hipMemcpyAsync(c->vox_buf.p, voxels, bytes, hipMemcpyHostToDevice, c->stream));
+  rc = begin_new_volume(c, true);
+  if (rc) return rc;
+  Volume& v = *c->vol;
+  HIP_TRY(v.vox_buf.reserve(bytes));
+  HIP_TRY(hipMemcpyAsync(v.vox_buf.p, voxels, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
-  c->rx = rx; c->ry = ry; c->rz = rz;
-  c->accel_iso = -1;
-  return RM_OK;
+  v.d_vox = static_cast<const uint8_t*>(v.vox_buf.p);
+  v.rx = rx; v.ry = ry; v.rz = rz;
+  return broadcast_volume(c);
 }
 
 int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz) {
@@ -474,9 +528,56 @@ int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz
   if (!d_voxels) return fail(RM_EINVAL, "d_voxels is NULL");
   rc = check_res(rx, ry, rz);
   if (rc) return rc;
-  c->d_vox = static_cast<const uint8_t*>(d_voxels);
-  c->rx = rx; c->ry = ry; c->rz = rz;
-  c->accel_iso = -1;
+  rc = begin_new_volume(c, true);
+  if (rc) return rc;
+  Volume& v = *c->vol;
+  v.d_vox = static_cast<const uint8_t*>(d_voxels);
+  v.rx = rx; v.ry = ry; v.rz = rz;
+  return broadcast_volume(c);
+}
+
+int rm_invalidate_volume(rm_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  {
+    std::lock_guard<std::mutex> lock(c->vol->mu);
+    bump_generation(*c->vol);
+  }
+  c->dev_src = nullptr;
+  return broadcast_volume(c);
+}
+
+int rm_share_volume(rm_ctx* dst, rm_ctx* src) {
+  int rc = check_ctx(dst);
+  if (rc) return rc;
+  if (!src || !have_volume(src)) return fail(RM_ESTATE, "rm_share_volume: the source context has no volume");
+  if (src->device != dst->device)
+    return fail(RM_EINVAL, "rm_share_volume: contexts are on devices %d and %d", src->device, dst->device);
+  if (!dst->peers.empty() || dst->parent) return fail(RM_EINVAL, "rm_share_volume: multi-device context");
+  dst->vol = src->vol;
+  dst->dev_src = nullptr;
+  dst->dev_recs.clear();
+  return RM_OK;
+}
+
+// shared tail of the device-side volume producers: optional copy back, make resident
+static int adopt_generated(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out) {
+  Volume& v = *c->vol;
+  const size_t bytes = (size_t)rx * ry * rz;
+  if (voxels_out)
+    HIP_TRY(hipMemcpyAsync(voxels_out, v.vox_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  v.d_vox = static_cast<const uint8_t*>(v.vox_buf.p);
+  v.rx = rx; v.ry = ry; v.rz = rz;
+  return broadcast_volume(c);
+}
+// shared head: fresh volume state with room for the bytes
+static int begin_generated(rm_ctx* c, size_t bytes) {
+  int rc = begin_new_volume(c, true);
+  if (rc) return rc;
+  c->vol->d_vox = nullptr;
+  HIP_TRY(c->vol->vox_buf.reserve(bytes));
   return RM_OK;
 }
 
@@ -485,28 +586,10 @@ int rm_make_gyroid_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out
   if (rc) return rc;
   rc = check_res(rx, ry, rz);
   if (rc) return rc;
-  const size_t bytes = (size_t)rx * ry * rz;
-  HIP_TRY(c->vox_buf.reserve(bytes));
-  HIP_TRY(rmk::launch_gyroid(c->stream, static_cast<uint8_t*>(c->vox_buf.p), rx, ry, rz));
-  if (voxels_out)
-    HIP_TRY(hipMemcpyAsync(voxels_out, c->vox_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
-  c->rx = rx; c->ry = ry; c->rz = rz;
-  c->accel_iso = -1;
-  return RM_OK;
-}
-
-// shared tail of the device-side volume producers: optional copy back, make resident
-static int adopt_generated(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out) {
-  const size_t bytes = (size_t)rx * ry * rz;
-  if (voxels_out)
-    HIP_TRY(hipMemcpyAsync(voxels_out, c->vox_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->d_vox = static_cast<const uint8_t*>(c->vox_buf.p);
-  c->rx = rx; c->ry = ry; c->rz = rz;
-  c->accel_iso = -1;
-  return RM_OK;
+  rc = begin_generated(c, (size_t)rx * ry * rz);
+  if (rc) return rc;
+  HIP_TRY(rmk::launch_gyroid(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p), rx, ry, rz));
+  return adopt_generated(c, rx, ry, rz, voxels_out);
 }
 
 int rm_make_terrain_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_out) {
@@ -515,8 +598,9 @@ int rm_make_terrain_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_ou
   rc = check_res(rx, ry, rz);
   if (rc) return rc;
   if (rx < 4 || rz < 4) return fail(RM_EINVAL, "terrain needs rx, rz >= 4 (walls are 4 voxels thick)");
-  HIP_TRY(c->vox_buf.reserve((size_t)rx * ry * rz));
-  HIP_TRY(rmk::launch_terrain(c->stream, static_cast<uint8_t*>(c->vox_buf.p), rx, ry, rz));
+  rc = begin_generated(c, (size_t)rx * ry * rz);
+  if (rc) return rc;
+  HIP_TRY(rmk::launch_terrain(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p), rx, ry, rz));
   return adopt_generated(c, rx, ry, rz, voxels_out);
 }
 
@@ -545,13 +629,13 @@ int rm_voxelize_vertices(rm_ctx* c, const double* xyz, long long n_vertices, int
   double off[3] = {0, 0, 0};
   for (int k = 0; k < 3; k++) off[k] = (0.5 * (double)res) * (1.0 - size[k] / md);
   const double s = n_vertices > 0 ? (double)res / md : 1.0;
-  const size_t bytes = (size_t)res * res * res;
-  HIP_TRY(c->vox_buf.reserve(bytes));
+  rc = begin_generated(c, (size_t)res * res * res);
+  if (rc) return rc;
   if (n_vertices > 0) {
     HIP_TRY(c->gen_buf.reserve((size_t)n_vertices * 24));
     HIP_TRY(hipMemcpyAsync(c->gen_buf.p, xyz, (size_t)n_vertices * 24, hipMemcpyHostToDevice, c->stream));
   }
-  HIP_TRY(rmk::launch_splat(c->stream, static_cast<uint8_t*>(c->vox_buf.p),
+  HIP_TRY(rmk::launch_splat(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p),
                             static_cast<const double*>(c->gen_buf.p), n_vertices, lo, off, s, res, ks));
   return adopt_generated(c, res, res, res, voxels_out);
 }
@@ -563,10 +647,11 @@ int rm_make_heatmap_volume(rm_ctx* c, const uint32_t* argb, int res, double amp,
   if (rc) return rc;
   if (!argb) return fail(RM_EINVAL, "argb is NULL");
   if (amp != amp) return fail(RM_EINVAL, "amp is NaN");
-  HIP_TRY(c->vox_buf.reserve((size_t)res * res * res));
+  rc = begin_generated(c, (size_t)res * res * res);
+  if (rc) return rc;
   HIP_TRY(c->gen_buf.reserve((size_t)res * res * 4));
   HIP_TRY(hipMemcpyAsync(c->gen_buf.p, argb, (size_t)res * res * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(rmk::launch_heatmap(c->stream, static_cast<uint8_t*>(c->vox_buf.p),
+  HIP_TRY(rmk::launch_heatmap(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p),
                               static_cast<const uint32_t*>(c->gen_buf.p), res, amp));
   return adopt_generated(c, res, res, res, voxels_out);
 }
@@ -604,51 +689,107 @@ int rm_tonemap_image(rm_ctx* c, const float* pixels, const void* opts544, uint32
   return RM_OK;
 }
 
-int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
-                    float* pixels_out, uint32_t* argb_out) {
-  int rc = check_ctx(c);
-  if (rc) return rc;
-  if (!opts_array || !mc_array) return fail(RM_EINVAL, "NULL buffer");
-  if (iter <= 0) return fail(RM_EINVAL, "iter = %d", iter);
-  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
-  for (int i = 0; i < iter; i++) {
-    rc = check_opts(c, static_cast<const char*>(opts_array) + (size_t)i * RM_OPTS_BYTES, n);
-    if (rc) return rc;
-  }
-  if (n == 0) return RM_OK;
+// upload the frame's records and tables to one device (asynchronous on its stream)
+static int upload_frame_inputs(rm_ctx* c, const void* opts_array, const float* mc_array, int iter) {
   HIP_TRY(c->opts_buf.reserve((size_t)iter * RM_OPTS_BYTES));
   HIP_TRY(c->mc_buf.reserve((size_t)iter * RM_TABLE_FLOATS * 4));
-  HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
-  if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
   HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts_array, (size_t)iter * RM_OPTS_BYTES,
                          hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->mc_buf.p, mc_array, (size_t)iter * RM_TABLE_FLOATS * 4,
                          hipMemcpyHostToDevice, c->stream));
-  RmOpts o0;
-  memcpy(&o0, opts_array, sizeof o0);
-  const int tiles = rmk::tiles_total(o0.resolution[0], n);
-  HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
-  std::vector<unsigned char> same;
-  records_same_as_prev(opts_array, iter, &same);
-  std::vector<RmOpts> recs(iter);
-  memcpy(recs.data(), opts_array, (size_t)iter * RM_OPTS_BYTES);
-  std::vector<int> isos(iter);
-  for (int i = 0; i < iter; i++)
-    isos[i] = static_cast<const uint8_t*>(opts_array)[(size_t)i * RM_OPTS_BYTES + offsetof(RmOpts, isoVal)];
-  rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
-                       static_cast<const float*>(c->mc_buf.p), o0.resolution[0], iter, n, 0, 1,
-                       static_cast<float*>(c->tile_buf.p), isos.data(), same.data(), recs.data());
-  if (rc) return rc;
-  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
+  return RM_OK;
+}
+
+// rm_render_frame over the devices of a multi-device context: device r renders the image
+// tiles r, r+N, ... (interleaved: cost per tile is very uneven) into tile-major accumulators,
+// the root collects them with one peer copy per device (xGMI, all links into the root
+// concurrently) and un-permutes + tonemaps.
+static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
+                              const RmOpts* recs, const unsigned char* same, float* pixels_out,
+                              uint32_t* argb_out, bool sdf) {
+  const int world = 1 + (int)c->peers.size();
+  const int resx = recs[0].resolution[0];
+  const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), world);
+  const size_t part_bytes = (size_t)tpp * 64 * 16;
+  HIP_TRY(c->tile_buf.reserve(part_bytes * world));
+  for (int r = 0; r < world; r++) {
+    rm_ctx* d = r == 0 ? c : c->peers[r - 1];
+    HIP_TRY(hipSetDevice(d->device));
+    int rc = upload_frame_inputs(d, opts_array, mc_array, iter);
+    if (rc) return rc;
+    FrameOut out;
+    if (r > 0) HIP_TRY(d->tile_buf.reserve(part_bytes));
+    out.acc = static_cast<float*>(r == 0 ? c->tile_buf.p : d->tile_buf.p);
+    out.tile_first = r;
+    out.tile_stride = world;
+    rc = frame_on_device(d, static_cast<const RmOpts*>(d->opts_buf.p), static_cast<const float*>(d->mc_buf.p),
+                         resx, iter, n, out, same, recs, sdf);
+    if (rc) return rc;
+    if (r > 0) {
+      HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(c->tile_buf.p) + part_bytes * r, c->device, d->tile_buf.p,
+                                 d->device, part_bytes, d->stream));
+      HIP_TRY(hipEventRecord(d->ev_done, d->stream));
+    }
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  for (rm_ctx* p : c->peers) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_done, 0));
+  if (pixels_out) HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
+  if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
+  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp,
                               static_cast<const RmOpts*>(c->opts_buf.p),
                               pixels_out ? static_cast<float*>(c->pix_buf.p) : nullptr,
                               argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr, n));
+  return RM_OK;
+}
+
+static int render_frame_host(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
+                             float* pixels_out, uint32_t* argb_out, bool sdf) {
+  std::vector<RmOpts> recs(iter);
+  memcpy(recs.data(), opts_array, (size_t)iter * RM_OPTS_BYTES);
+  const int resx = recs[0].resolution[0];
+  std::vector<unsigned char> same;
+  records_same_as_prev(opts_array, iter, &same);
+  if (!c->peers.empty() && !sdf) {
+    int rc = render_frame_multi(c, opts_array, mc_array, iter, n, recs.data(), same.data(), pixels_out,
+                                argb_out, sdf);
+    if (rc) return rc;
+  } else {
+    int rc = upload_frame_inputs(c, opts_array, mc_array, iter);
+    if (rc) return rc;
+    // one device: the frame kernel keeps the image row-major and tonemaps with the last pass
+    HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
+    if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
+    FrameOut out;
+    out.acc = static_cast<float*>(c->pix_buf.p);
+    out.argb = argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr;
+    out.row_major = true;
+    rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p), static_cast<const float*>(c->mc_buf.p),
+                         resx, iter, n, out, same.data(), recs.data(), sdf);
+    if (rc) return rc;
+  }
   if (pixels_out)
     HIP_TRY(hipMemcpyAsync(pixels_out, c->pix_buf.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
   if (argb_out)
     HIP_TRY(hipMemcpyAsync(argb_out, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
+}
+
+int rm_render_frame(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
+                    float* pixels_out, uint32_t* argb_out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!opts_array || !mc_array) return fail(RM_EINVAL, "NULL buffer");
+  if (iter <= 0) return fail(RM_EINVAL, "iter = %d", iter);
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  {
+    std::vector<RmOpts> recs(iter);
+    memcpy(recs.data(), opts_array, (size_t)iter * RM_OPTS_BYTES);
+    rc = check_frame_opts(c, recs.data(), iter, n, recs[0].resolution[0]);
+    if (rc) return rc;
+  }
+  if (n == 0) return RM_OK;
+  return render_frame_host(c, opts_array, mc_array, iter, n, pixels_out, argb_out, false);
 }
 
 int rm_set_sdf_volume(rm_ctx* c, const float* sdf, int rx, int ry, int rz) {
@@ -679,42 +820,16 @@ int rm_render_sdf_frame(rm_ctx* c, const void* opts_array, const float* mc_array
     const RmOpts& o = recs[i];
     if (o.resolution[0] <= 0 || o.resolution[1] <= 0)
       return fail(RM_EINVAL, "TRenderOpts.resolution = (%d,%d)", o.resolution[0], o.resolution[1]);
+    if (o.resolution[0] != recs[0].resolution[0])
+      return fail(RM_EINVAL, "record %d: resolution.x = %d but the frame is %d wide", i, o.resolution[0],
+                  recs[0].resolution[0]);
     if (o.voxelRes[0] != c->sdf_rx || o.voxelRes[1] != c->sdf_ry || o.voxelRes[2] != c->sdf_rz)
       return fail(RM_EINVAL, "TRenderOpts.voxelRes = (%d,%d,%d) does not match the distance field %dx%dx%d",
                   o.voxelRes[0], o.voxelRes[1], o.voxelRes[2], c->sdf_rx, c->sdf_ry, c->sdf_rz);
     if (o.numLights > 4) return fail(RM_EINVAL, "TRenderOpts.numLights = %d (max 4)", (int)o.numLights);
   }
   if (n == 0) return RM_OK;
-  HIP_TRY(c->opts_buf.reserve((size_t)iter * RM_OPTS_BYTES));
-  HIP_TRY(c->mc_buf.reserve((size_t)iter * RM_TABLE_FLOATS * 4));
-  HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
-  if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
-  HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts_array, (size_t)iter * RM_OPTS_BYTES,
-                         hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->mc_buf.p, mc_array, (size_t)iter * RM_TABLE_FLOATS * 4,
-                         hipMemcpyHostToDevice, c->stream));
-  const int resx = recs[0].resolution[0];
-  const int tiles = rmk::tiles_total(resx, n);
-  HIP_TRY(c->tile_buf.reserve((size_t)tiles * 64 * 16));
-  std::vector<unsigned char> same;
-  records_same_as_prev(opts_array, iter, &same);
-  std::vector<int> isos(iter, 0);
-  c->sdf_frame = true;
-  rc = frame_on_device(c, static_cast<const RmOpts*>(c->opts_buf.p),
-                       static_cast<const float*>(c->mc_buf.p), resx, iter, n, 0, 1,
-                       static_cast<float*>(c->tile_buf.p), isos.data(), same.data(), recs.data());
-  c->sdf_frame = false;
-  if (rc) return rc;
-  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), 1, tiles,
-                              static_cast<const RmOpts*>(c->opts_buf.p),
-                              pixels_out ? static_cast<float*>(c->pix_buf.p) : nullptr,
-                              argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr, n));
-  if (pixels_out)
-    HIP_TRY(hipMemcpyAsync(pixels_out, c->pix_buf.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-  if (argb_out)
-    HIP_TRY(hipMemcpyAsync(argb_out, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return RM_OK;
+  return render_frame_host(c, opts_array, mc_array, iter, n, pixels_out, argb_out, true);
 }
 
 int rm_tiles_per_part(int resx, int n, int parts) {
@@ -726,28 +841,38 @@ int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int wid
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!d_opts || iter <= 0) return fail(RM_EINVAL, "d_opts NULL or iter = %d", iter);
-  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (n <= 0 || width <= 0) return fail(RM_EINVAL, "n = %d, width = %d", n, width);
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
   std::vector<RmOpts> recs(iter);
   HIP_TRY(hipMemcpyAsync(recs.data(), d_opts, (size_t)iter * RM_OPTS_BYTES, hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  c->dev_iso.clear();
-  c->dev_iso_src = nullptr;
-  for (int i = 0; i < iter; i++) {
-    rc = check_opts(c, &recs[i], n);
-    if (rc) return rc;
-    if (recs[i].resolution[0] != width)
-      return fail(RM_EINVAL, "record %d: resolution.x = %d but width = %d", i, recs[i].resolution[0], width);
-    c->dev_iso.push_back(recs[i].isoVal);
-  }
+  c->dev_src = nullptr;
+  rc = check_frame_opts(c, recs.data(), iter, n, width);
+  if (rc) return rc;
   records_same_as_prev(recs.data(), iter, &c->dev_same);
   c->dev_recs = recs;
-  c->dev_iso_src = d_opts;
+  c->dev_iter = iter;
+  c->dev_n = n;
+  c->dev_width = width;
+  c->dev_generation = c->vol->generation;
   // build the derived structures of the (first) hit threshold now, not inside the first frame
   rmk::Accel accel;
   rc = ensure_accel(c, recs[0].isoVal, &accel);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->dev_src = d_opts;
+  return RM_OK;
+}
+
+// what rm_check_device_opts accepted is still what this call describes
+static int check_validated(rm_ctx* c, const void* d_opts, int iter, int n, int width) {
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (c->dev_src != d_opts || c->dev_iter != iter || c->dev_n != n || c->dev_width != width ||
+      c->dev_generation != c->vol->generation)
+    return fail(RM_ESTATE,
+                "rm_check_device_opts(d_opts, iter=%d, n=%d, width=%d) must validate the records against the "
+                "resident volume first (and again after either changes)", iter, n, width);
   return RM_OK;
 }
 
@@ -759,12 +884,31 @@ int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, 
   if (iter <= 0 || n <= 0 || width <= 0) return fail(RM_EINVAL, "iter = %d, n = %d, width = %d", iter, n, width);
   if (tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
     return fail(RM_EINVAL, "tile partition (%d,%d)", tile_first, tile_stride);
-  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
-  if (c->dev_iso_src != d_opts || (int)c->dev_iso.size() != iter)
-    return fail(RM_ESTATE, "rm_check_device_opts(d_opts, iter=%d, ...) must validate the records first", iter);
-  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, tile_first,
-                         tile_stride, d_tiles, c->dev_iso.data(), c->dev_same.data(),
-                         c->dev_recs.data());
+  rc = check_validated(c, d_opts, iter, n, width);
+  if (rc) return rc;
+  FrameOut out;
+  out.acc = d_tiles;
+  out.tile_first = tile_first;
+  out.tile_stride = tile_stride;
+  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, out, c->dev_same.data(),
+                         c->dev_recs.data(), false);
+}
+
+int rm_frame_device_full(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, int n, int width,
+                         float* d_pixels, uint32_t* d_argb) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_opts || !d_mc || (!d_pixels && !d_argb)) return fail(RM_EINVAL, "NULL device buffer");
+  if (iter <= 0 || n <= 0 || width <= 0) return fail(RM_EINVAL, "iter = %d, n = %d, width = %d", iter, n, width);
+  rc = check_validated(c, d_opts, iter, n, width);
+  if (rc) return rc;
+  FrameOut out;
+  if (!d_pixels) HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
+  out.acc = d_pixels ? d_pixels : static_cast<float*>(c->pix_buf.p);
+  out.argb = d_argb;
+  out.row_major = true;
+  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, out, c->dev_same.data(),
+                         c->dev_recs.data(), false);
 }
 
 int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void* d_opts, int n,
@@ -791,25 +935,26 @@ int rm_last_frame_timing(rm_ctx* c, float* ms, int* launches) {
   return RM_OK;
 }
 
+int rm_last_table_build_ms(rm_ctx* c, float* ms) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!have_volume(c) || c->vol->accel_iso < 0) return fail(RM_ESTATE, "no derived tables have been built");
+  if (ms) *ms = (float)c->vol->accel_build_ms;
+  return RM_OK;
+}
+
 int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
   if (iso < 0 || iso > 255) return fail(RM_EINVAL, "iso = %d", iso);
   if (!c->use_accel) return fail(RM_ESTATE, "acceleration structures are disabled (RAYMARCH_NO_ACCEL)");
   rmk::Accel accel;
   rc = ensure_accel(c, iso, &accel);
   if (rc) return rc;
-  const size_t vox = (size_t)c->rx * c->ry * c->rz;
-#if RM_BRICKS
-  if (dist_out) {  // what the kernels read, converted back to row-major
-    HIP_TRY(rmk::launch_brick(c->stream, static_cast<uint8_t*>(c->tmp_buf.p), c->rx, c->ry, c->rz,
-                              const_cast<uint8_t*>(accel.dist), false));
-    HIP_TRY(hipMemcpyAsync(dist_out, c->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
-  }
-#else
+  if (!accel.dist) return fail(RM_ESTATE, "derived tables are not built for this volume size");
+  const size_t vox = (size_t)c->vol->rx * c->vol->ry * c->vol->rz;
   if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
-#endif
   if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
@@ -818,24 +963,15 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
 int rm_debug_get_octants(rm_ctx* c, int iso, uint8_t* oct_out) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!c->d_vox) return fail(RM_ESTATE, "rm_set_volume has not been called");
+  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
   if (iso < 0 || iso > 255 || !oct_out) return fail(RM_EINVAL, "bad argument");
   rmk::Accel accel;
   rc = ensure_accel(c, iso, &accel);
   if (rc) return rc;
   if (!accel.dist || !accel.oct_stride)
     return fail(RM_ESTATE, "directional tables are not built (disabled, or volume too large)");
-  const size_t vox = (size_t)c->rx * c->ry * c->rz;
-#if RM_BRICKS
-  for (int t = 0; t < 8; t++) {
-    HIP_TRY(rmk::launch_brick(c->stream, static_cast<uint8_t*>(c->tmp_buf.p), c->rx, c->ry, c->rz,
-                              const_cast<uint8_t*>(accel.dist) + (size_t)(t + 1) * accel.oct_stride, false));
-    HIP_TRY(hipMemcpyAsync(oct_out + (size_t)t * vox, c->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  }
-#else
+  const size_t vox = (size_t)c->vol->rx * c->vol->ry * c->vol->rz;
   HIP_TRY(hipMemcpyAsync(oct_out, accel.dist + vox, vox * 8, hipMemcpyDeviceToHost, c->stream));
-#endif
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }

@@ -19,7 +19,6 @@
 
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
-#include "rm_wave.hpp"
 
 #if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
 // debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
@@ -100,299 +99,161 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   }
 }
 
-// All passes of a frame in ONE launch: blockIdx.y = pass, blockIdx.x covers the
-// partition's tiles.  Samples of different passes are independent until the
-// blend, so each lane writes its colour*exposure to a staging slot
-// [pass][local tile][lane] and blend_kernel applies the reference's in-order
-// recurrence afterwards.  Compared with one launch per pass this removes the
-// per-pass tail (waves of the next pass fill the CUs while expensive tiles of
-// the previous one finish) and costs the same 32 B per sample the reference
-// spends on its read-modify-write of the accumulator.
-// Lane -> (pixel, pass).  With pp = 1 a wavefront is one 8x8 tile of one pass.
-// With pp = 2^k > 1 (possible when the passes' records differ only in .time) it
-// is a (64/pp)-pixel block of the tile times pp consecutive passes: lanes that
-// trace the SAME pixel with different jitter follow almost the same control flow,
-// which is what a 64-wide SIMT machine wants -- neighbouring pixels of one pass
-// diverge far more (sky / surface / reflection) than passes of one pixel.
+// The frame kernel: ALL RenderImage passes of a frame for a partition of the image, blended in
+// the reference's order, in one launch (renderer.cl:478-494 applied pass after pass,
+// core.clj:81-90) -- and, for an unpartitioned image, TonemapImage as well (renderer.cl:496-508).
+//
+// Lane -> (pixel, pass).  With pp = 2^pp_log2 passes per wavefront a wavefront owns 64/pp pixels
+// of one 8x8 tile and walks through the frame's passes pp at a time: lane l traces pixel l / pp
+// in pass c0 + l % pp.  (pp > 1 needs records that differ in .time only, which is what the
+// reference's host produces, core.clj:99-106.)  Lanes that trace the SAME pixel with different
+// jitter follow almost the same control flow, which is what a 64-wide SIMT machine wants --
+// neighbouring pixels of one pass diverge far more (sky / surface / reflection).
+//
+// Blend: the reference's accumulator update p <- mix(p, c, frameBlend) is an in-order
+// recurrence over the passes (exponential, not a mean).  The pp colours of a pixel
+// sit in pp neighbouring lanes: they go through LDS to the pixel's first lane, which applies
+// the recurrence in pass order and carries p in registers from one group of passes to the
+// next.  One float4 per pixel leaves the kernel; nothing is staged per pass.
+struct FrameArgs {
+  const uint8_t* __restrict__ vox;
+  const uint8_t* __restrict__ dist8;
+  const uint32_t* __restrict__ surf32;
+  unsigned long long oct_stride;
+  const float* __restrict__ sdf;
+  const float4* __restrict__ mc_all;   // scatter table of the launch's first pass
+  const RmOpts* __restrict__ opts_all; // record of the launch's first pass
+  const RmOpts* __restrict__ opts0;    // record 0 of the frame (TonemapImage reads its gamma)
+  float4* __restrict__ acc;            // tile-major partition accumulators, or the row-major image
+  uint32_t* __restrict__ argb;         // row-major ARGB, or nullptr
+  int n, resx, tile_first, tile_stride, tiles_per_part, pp_log2, passes, bpr;
+  int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
+  int row_major;                       // acc is indexed by work-item id instead of slot*64 + pixel
+};
+
+__device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, float g) {
+  const float c[3] = {px, py, pz};
+  uint32_t ch[3];
+  for (int k = 0; k < 3; k++) {
+    const float t = c[k] / (g + c[k]);
+    const float v = t * t * 255.0f;
+    ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
+  }
+  return 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
+}
+
 template <bool ACCEL, int MINW, bool SDFM = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_samples_kernel(
-    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
-    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
-    const RmOpts* __restrict__ opts_all, float4* __restrict__ staging, int n, int tile_first,
-    int tile_stride, int tiles_per_part, int pp_log2, int bpr, unsigned long long oct_stride,
-    const float* __restrict__ sdf = nullptr) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
+  using Tr = rmk::Tracer<false, ACCEL, SDFM>;
+  const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
-  const int pass0 = blockIdx.y * pp;
-  const RmOpts* __restrict__ opts = opts_all + pass0;  // uniform record (pp > 1: all equal but .time)
-  const int resx = opts->resolution[0];
-  const TileGeom g = tile_geom(resx, n);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const TileGeom g = tile_geom(a.resx, a.n);
+  const int lane = threadIdx.x & 63;
   // XCD-aware order (bpr > 0): the dispatcher deals consecutive workgroups to the 8
   // XCDs round-robin, each with its own L2.  Hardware block b = 8*m + k is given the
   // logical block of tile row 8*(m / bpr) + k, so XCD k renders every 8th tile ROW:
   // its primary rays sweep an eighth of the volume's slabs instead of all of them,
   // while rows stay interleaved finely enough to balance the load.
   long long lb = blockIdx.x;
-  if (bpr > 0) {
+  if (a.bpr > 0) {
     const long long m = lb >> 3, k = lb & 7;
-    lb = ((m / bpr) * 8 + k) * bpr + (m % bpr);
+    lb = ((m / a.bpr) * 8 + k) * a.bpr + (m % a.bpr);
   }
   // wavefronts of a tile are consecutive: tile slot = w / pp, sub-block = w % pp
-  const long long w = lb * kWavesPerBlock + wave;
-  const long long slot = w >> pp_log2;
-  const int sub = (int)(w & (pp - 1));
-  const long long tile = tile_first + slot * tile_stride;
+  const long long slot = lb >> pp_log2;
+  const int sub = (int)(lb & (pp - 1));
+  if (slot >= a.tiles_per_part) return;  // padding of the XCD-aware grid
+  const long long tile = a.tile_first + slot * a.tile_stride;
   if (tile >= g.tiles_total) return;
-  const int pass = pass0 + (lane & (pp - 1));
   // Z-order inside the tile, so that any 2^k consecutive pixels form a compact block
   const int z = sub * ppw + (lane >> pp_log2);
   const int zx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
   const int zy = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
   const int pix = zy * 8 + zx;  // 0..63 within the tile, row-major 8x8
-  const int id = lane_pixel((int)tile, pix, resx, g.tiles_x, n, 0, n);
-  if (id < 0) return;
-  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32, oct_stride, sdf};
-  rmk::Tracer<false, ACCEL, SDFM> tr(sc);
-  if (pp > 1) tr.set_pass(mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts_all[pass].time);
-#if RM_WAVE_SHARE
-  static_assert(kWavesPerBlock == 1, "the shared phases use one LDS block per workgroup");
-  __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 1];
-  const rmk::v3 col = ACCEL ? tr.shade_wave(id, wave_lds) : tr.shade(id);
-#else
-  const rmk::v3 col = tr.shade(id);
-#endif
-  staging[((long long)pass * tiles_per_part + slot) * 64 + pix] = make_float4(col.x, col.y, col.z, 1.0f);
-#ifdef RM_PHASE_CLOCK
-  for (int k = 0; k < 5; k++)
-    if (tr.ws_clk[k]) atomicAdd(&g_work_stats[32 + k], tr.ws_clk[k]);
-  if (tr.ws_now()) atomicAdd(&g_work_stats[37], 1ull);
-#endif
-#ifdef RM_WORK_STATS
-  {
-    atomicAdd(&g_work_stats[43], (unsigned long long)tr.ws_redo);
-    for (int k = 0; k < 3; k++) {
-      atomicAdd(&g_work_stats[48 + k], (unsigned long long)tr.ws_k_est[k]);
-      atomicAdd(&g_work_stats[52 + k], (unsigned long long)tr.ws_k_filt[k]);
-    }
-    for (int k = 0; k < 4; k++) atomicAdd(&g_work_stats[44 + k], (unsigned long long)tr.ws_k_nohit[k]);
-    atomicAdd(&g_work_stats[38], (unsigned long long)(tr.ws_k_one[0] + tr.ws_k_one[1]));
-    atomicAdd(&g_work_stats[39], (unsigned long long)tr.ws_k_one[2]);
-    atomicAdd(&g_work_stats[40], (unsigned long long)tr.ws_pairs);
-    atomicAdd(&g_work_stats[41], (unsigned long long)tr.ws_pairs_back);
-    atomicAdd(&g_work_stats[42], (unsigned long long)tr.ws_pairs_dark);
-    unsigned int v[32] = {1u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
-                          tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
-    for (int k = 0; k < 4; k++) {
-      v[11 + k] = tr.ws_k_walks[k];
-      v[15 + k] = tr.ws_k_fetch[k];
-      v[19 + k] = tr.ws_k_slots[k];
-    }
-    for (int k = 0; k < 6; k++) v[23 + k] = tr.ws_dhist[k];
-    v[29] = tr.ws_adds_hit; v[30] = tr.ws_adds_nohit; v[31] = tr.ws_adds_lazy;
-    for (int k = 0; k < 32; k++) atomicAdd(&g_work_stats[k], (unsigned long long)v[k]);
+  const int id = lane_pixel((int)tile, pix, a.resx, g.tiles_x, a.n, 0, a.n);
+  if (id < 0) return;  // (all pp lanes of a pixel leave together)
+  static_assert(kWavesPerBlock == 1, "the LDS areas below belong to one wavefront");
+  // (the colours of a group are exchanged through the area of the shared phases, whose posted
+  //  values are dead once shade_wave() has returned)
+  __shared__ float wave_lds[ACCEL ? Tr::kWaveLdsFloats : 3 * 64];
+  float* const blend_lds = wave_lds;
+  const int pl = lane & (pp - 1);  // this lane's pass within a group
+  const bool first = pl == 0;      // the lane that keeps its pixel's accumulator
+  const long long at = a.row_major ? (long long)id : slot * 64 + pix;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (a.accumulate && first) {
+    const float4 p = a.acc[at];
+    px = p.x; py = p.y; pz = p.z;
   }
+#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
+  unsigned long long ws_acc[64];
+  for (int k = 0; k < 64; k++) ws_acc[k] = 0ull;
 #endif
-}
-
-// The two halves of a sample (Tracer::trace_chain / shade_from_hits): same grid
-// and tile order as render_samples_kernel, hit records in HBM in between.
-template <int MINW>
-__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void trace_chain_kernel(
-    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
-    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
-    const RmOpts* __restrict__ opts_all, float4* __restrict__ hits, int n, int tile_first,
-    int tile_stride, int tiles_per_part) {
-  const int pass = blockIdx.y;
-  const RmOpts* __restrict__ opts = opts_all + pass;
-  const int resx = opts->resolution[0];
-  const TileGeom g = tile_geom(resx, n);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
-  const long long tile = tile_first + slot * tile_stride;
-  if (tile >= g.tiles_total) return;
-  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, 0, n);
-  if (id < 0) return;
-  rmk::Scene sc{vox, mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts, dist8, surf32};
-  rmk::Tracer<false, true> tr(sc);
-  const size_t samples = (size_t)gridDim.y * tiles_per_part * 64;
-  tr.trace_chain(id, hits, samples, ((size_t)pass * tiles_per_part + slot) * 64 + lane);
-}
-
-template <int MINW>
-__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void light_kernel(
-    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
-    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
-    const RmOpts* __restrict__ opts_all, const float4* __restrict__ hits,
-    float4* __restrict__ staging, int n, int tile_first, int tile_stride, int tiles_per_part) {
-  const int pass = blockIdx.y;
-  const RmOpts* __restrict__ opts = opts_all + pass;
-  const int resx = opts->resolution[0];
-  const TileGeom g = tile_geom(resx, n);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long slot = (long long)blockIdx.x * kWavesPerBlock + wave;
-  const long long tile = tile_first + slot * tile_stride;
-  if (tile >= g.tiles_total) return;
-  const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, 0, n);
-  if (id < 0) return;
-  rmk::Scene sc{vox, mc_all + (size_t)pass * RM_TABLE_ENTRIES, opts, dist8, surf32};
-  rmk::Tracer<false, true> tr(sc);
-  const size_t samples = (size_t)gridDim.y * tiles_per_part * 64;
-  const size_t sidx = ((size_t)pass * tiles_per_part + slot) * 64 + lane;
-  const rmk::v3 col = tr.shade_from_hits(id, hits, samples, sidx);
-  staging[sidx] = make_float4(col.x, col.y, col.z, 1.0f);
-}
-
-// Three-phase form (Tracer::trace_chain / point_rays / shade_from_rays).  All three use
-// the pass-packed lane mapping of render_samples_kernel; phase 2 has a z dimension
-// over the shading levels (0 = primary hit, k = reflection k).
-struct LaneMap { int id, pass; long long sidx; };
-__device__ __forceinline__ LaneMap lane_map(const RmOpts* opts_all, int n, int tile_first, int tile_stride,
-                                            int tiles_per_part, int pp_log2) {
-  LaneMap r;
-  r.id = -1;
-  const int pp = 1 << pp_log2, ppw = 64 >> pp_log2;
-  const int pass0 = blockIdx.y * pp;
-  const int resx = opts_all[pass0].resolution[0];
-  const TileGeom g = tile_geom(resx, n);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long w = (long long)blockIdx.x * kWavesPerBlock + wave;
-  const long long slot = w >> pp_log2;
-  const int sub = (int)(w & (pp - 1));
-  const long long tile = tile_first + slot * tile_stride;
-  r.pass = pass0 + (lane & (pp - 1));
-  r.sidx = 0;
-  if (tile >= g.tiles_total) return r;
-  const int z = sub * ppw + (lane >> pp_log2);
-  const int zx = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
-  const int zy = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-  const int pix = zy * 8 + zx;
-  r.id = lane_pixel((int)tile, pix, resx, g.tiles_x, n, 0, n);
-  r.sidx = ((long long)r.pass * tiles_per_part + slot) * 64 + pix;
-  return r;
-}
-
-template <int PHASE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 8) void phase_kernel(
-    const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
-    const uint32_t* __restrict__ surf32, const float4* __restrict__ mc_all,
-    const RmOpts* __restrict__ opts_all, float4* __restrict__ hits, float2* __restrict__ rays,
-    float4* __restrict__ staging, int n, int tile_first, int tile_stride, int tiles_per_part,
-    int pp_log2, int iter) {
-  const LaneMap lm = lane_map(opts_all, n, tile_first, tile_stride, tiles_per_part, pp_log2);
-  if (lm.id < 0) return;
-  const int pass0 = blockIdx.y << pp_log2;
-  const RmOpts* __restrict__ opts = opts_all + pass0;
-  rmk::Scene sc{vox, mc_all + (size_t)pass0 * RM_TABLE_ENTRIES, opts, dist8, surf32};
-  rmk::Tracer<false, true> tr(sc);
-  if (pp_log2 > 0) tr.set_pass(mc_all + (size_t)lm.pass * RM_TABLE_ENTRIES, opts_all[lm.pass].time);
-  const size_t samples = (size_t)iter * tiles_per_part * 64;
-  if (PHASE == 1) {
-    tr.trace_chain(lm.id, hits, samples, (size_t)lm.sidx);
-  } else if (PHASE == 2) {
-    const int level = blockIdx.z;
-    const float4* h = hits + ((size_t)level * samples + lm.sidx) * 2;
-    const float4 ha = h[0], hb = h[1];
-    const int obj = __float_as_int(hb.w);
-    rmk::v3 nrm = rmk::V(hb.x, hb.y, hb.z);
-    if (level == 0) {
-      if (ha.w >= opts->maxDist) return;  // primary miss
-      const rmk::Material m = rmk::material_of(*opts, obj);
-      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
-      nrm = rmk::mads(tr.sample_mc_normal(lm.id), k, nrm);  // renderer.cl:420
-    } else if (obj < 0) {
-      return;  // no such bounce / it left the scene
-    }
-    const auto s = tr.sample_seeds(lm.id);
-    rays[(size_t)level * samples + lm.sidx] = tr.point_rays(s, rmk::V(ha.x, ha.y, ha.z), nrm);
-  } else {
-    const rmk::v3 col = tr.shade_from_rays(lm.id, hits, rays, samples, (size_t)lm.sidx);
-    staging[lm.sidx] = make_float4(col.x, col.y, col.z, 1.0f);
-  }
-}
-
-// Persistent, wave-scheduled renderer (rm_wave.hpp): each wavefront pulls tiles
-// from a queue, keeps a pool of (pixel, pass) samples of its tile, and
-// alternates between one shared march loop and short per-lane continuations.
-constexpr int kMarchBudget = 2;  // lookups per lane between two ballots
-
-// MINW = waves per SIMD the register allocator must leave room for (2: no spills,
-// ~200 VGPRs; 4: 128 VGPRs with the cold lane state spilled to scratch).
-template <int MINW>
-__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_wave_kernel(rmk::WaveArgs a) {
-  rmk::WaveTracer T(a);
-  rmk::WaveLane L{};
-  L.st = rmk::S_IDLE;
-  L.marching = false;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const int pool = 64 * a.iter;
-  const TileGeom g = tile_geom(a.resx, a.n);
-  int slot = 0, next = pool;  // wave-uniform: current local tile, next sample of its pool
-  bool exhausted = false;
-  for (;;) {
-    // ---- hand samples to idle lanes
-    unsigned long long need = __ballot(L.st == rmk::S_IDLE);
-    while (need != 0ull && !exhausted) {
-      if (next >= pool) {
-        unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(a.queue, 1u);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= (unsigned int)a.my_tiles) { exhausted = true; break; }
-        slot = (int)t;
-        next = 0;
-      }
-      if (L.st == rmk::S_IDLE) {
-        const int s = next + __popcll(need & below);
-        if (s < pool) {
-          const int pass = s >> 6, pix = s & 63;
-          const long long tile = a.tile_first + (long long)slot * a.tile_stride;
-          const int id = lane_pixel((int)tile, pix, a.resx, g.tiles_x, a.n, 0, a.n);
-          if (id >= 0) {
-            L.id = id;
-            L.pass = pass;
-            L.out_idx = (pass * a.tiles_per_part + slot) * 64 + pix;
-            L.st = rmk::S_NEW;
-          }
+  for (int c0 = 0; c0 < a.passes; c0 += pp) {
+    const int pass = c0 + pl;
+    const bool live = pass < a.passes;
+    const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
+    rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
+    Tr tr(sc);
+    if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
+    rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
+    if (ACCEL) col = tr.shade_wave(id, wave_lds, live);
+    else if (live) col = tr.shade(id);
+    // mix(p, col, frameBlend) in pass order: renderer.cl:492
+    if (pp > 1) {
+      blend_lds[lane] = col.x; blend_lds[64 + lane] = col.y; blend_lds[128 + lane] = col.z;
+      __syncthreads();
+      if (first) {
+        const int cnt = min(pp, a.passes - c0);  // uniform
+        for (int k = 0; k < cnt; k++) {
+          const float fb = a.opts_all[c0 + k].frameBlend;
+          px = px + (blend_lds[lane + k] - px) * fb;
+          py = py + (blend_lds[64 + lane + k] - py) * fb;
+          pz = pz + (blend_lds[128 + lane + k] - pz) * fb;
         }
       }
-      next = min(pool, next + __popcll(need));
-      need = __ballot(L.st == rmk::S_IDLE);
-    }
-    // ---- vote: run whichever phase has more lanes ready for it
-    const bool wants_step = !L.marching && L.st != rmk::S_IDLE;
-    const unsigned long long mc = __ballot(wants_step);
-    const unsigned long long mm = __ballot(L.marching);
-    if ((mc | mm) == 0ull) {
-      if (exhausted) break;
-      continue;
-    }
-    if (__popcll(mc) * a.wait_lanes >= __popcll(mm) * 16) {
-      if (wants_step) T.advance(L);  // one continuation step
+      __syncthreads();
     } else {
-      if (L.marching) T.march_some(L, kMarchBudget);  // the shared march loop
+      const float fb = opts->frameBlend;
+      px = px + (col.x - px) * fb;
+      py = py + (col.y - py) * fb;
+      pz = pz + (col.z - pz) * fb;
     }
-  }
-}
-
-// In-order accumulation of the staged pass colours: p <- mix(p, c_i, frameBlend_i)
-// for i = 0..iter-1 starting from 0 (renderer.cl:492 applied pass after pass,
-// core.clj:81-90).  Lanes without a pixel hold garbage that nobody reads.
-__global__ __launch_bounds__(256) void blend_kernel(const float4* __restrict__ staging,
-                                                    const RmOpts* __restrict__ opts_all, int iter,
-                                                    long long count, float4* __restrict__ tiles) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += (long long)gridDim.x * blockDim.x) {
-    float px = 0.f, py = 0.f, pz = 0.f;
-    for (int k = 0; k < iter; k++) {
-      const float fb = opts_all[k].frameBlend;
-      const float4 c = staging[(long long)k * count + i];
-      px = px + (c.x - px) * fb;
-      py = py + (c.y - py) * fb;
-      pz = pz + (c.z - pz) * fb;
+#ifdef RM_PHASE_CLOCK
+    for (int k = 0; k < 5; k++) ws_acc[32 + k] += tr.ws_clk[k];
+    if (tr.ws_now()) ws_acc[37] += 1ull;
+#endif
+#ifdef RM_WORK_STATS
+    if (live) {
+      ws_acc[43] += tr.ws_redo;
+      for (int k = 0; k < 3; k++) { ws_acc[48 + k] += tr.ws_k_est[k]; ws_acc[52 + k] += tr.ws_k_filt[k]; }
+      for (int k = 0; k < 4; k++) ws_acc[44 + k] += tr.ws_k_nohit[k];
+      ws_acc[38] += tr.ws_k_one[0] + tr.ws_k_one[1];
+      ws_acc[39] += tr.ws_k_one[2];
+      ws_acc[40] += tr.ws_pairs; ws_acc[41] += tr.ws_pairs_back; ws_acc[42] += tr.ws_pairs_dark;
+      ws_acc[0] += 1;
     }
-    tiles[i] = make_float4(px, py, pz, 1.0f);
+    {
+      const unsigned int v[32] = {0u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
+                                  tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
+      for (int k = 1; k < 11; k++) ws_acc[k] += v[k];
+      for (int k = 0; k < 4; k++) {
+        ws_acc[11 + k] += tr.ws_k_walks[k]; ws_acc[15 + k] += tr.ws_k_fetch[k]; ws_acc[19 + k] += tr.ws_k_slots[k];
+      }
+      for (int k = 0; k < 6; k++) ws_acc[23 + k] += tr.ws_dhist[k];
+      ws_acc[29] += tr.ws_adds_hit; ws_acc[30] += tr.ws_adds_nohit; ws_acc[31] += tr.ws_adds_lazy;
+    }
+#endif
   }
+  if (first) {
+    a.acc[at] = make_float4(px, py, pz, 1.0f);
+    if (a.argb) a.argb[id] = tonemap_argb(px, py, pz, a.opts0->gamma);
+  }
+#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
+  for (int k = 0; k < 64; k++)
+    if (ws_acc[k]) atomicAdd(&g_work_stats[k], ws_acc[k]);
+#endif
 }
 
 __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ pixels,
@@ -402,14 +263,7 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
   for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n;
        id += (long long)gridDim.x * blockDim.x) {
     const float4 p = pixels[id];
-    const float c[3] = {p.x, p.y, p.z};
-    uint32_t ch[3];
-    for (int k = 0; k < 3; k++) {
-      const float t = c[k] / (g + c[k]);
-      const float v = t * t * 255.0f;
-      ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
-    }
-    argb[id] = 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
+    argb[id] = tonemap_argb(p.x, p.y, p.z, g);
   }
 }
 
@@ -432,16 +286,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
     const long long at = ((long long)(tile % parts) * tiles_per_part + tile / parts) * 64 + lane;
     const float4 p = tiles[at];
     if (pixels) pixels[id] = p;
-    if (argb) {
-      const float c[3] = {p.x, p.y, p.z};
-      uint32_t ch[3];
-      for (int k = 0; k < 3; k++) {
-        const float t = c[k] / (g + c[k]);
-        const float v = t * t * 255.0f;
-        ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
-      }
-      argb[id] = 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
-    }
+    if (argb) argb[id] = tonemap_argb(p.x, p.y, p.z, g);
   }
 }
 
@@ -554,192 +399,64 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   return hipGetLastError();
 }
 
-hipError_t launch_render_samples(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
-                                 const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
-                                 int tile_first, int tile_stride, int min_waves, int pp_log2,
-                                 bool xcd_rows) {
-  const TileGeom g = tile_geom(resx, n);
-  if (tile_stride < 1) tile_stride = 1;
+// log2 of the passes per wavefront for a run of `passes` records that differ in .time only:
+// the largest k <= max_log2 whose last group leaves at most ~15 % of the lane turns without a
+// pass (k = 0 never leaves any)
+int choose_pass_pack(int passes, int max_log2) {
+  for (int k = max_log2; k >= 1; k--) {
+    const int pp = 1 << k;
+    if ((double)(((passes + pp - 1) / pp) * pp) <= 1.15 * (double)passes) return k;
+  }
+  return 0;
+}
+
+hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
+  const TileGeom g = tile_geom(f.resx, f.n);
+  const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
   const long long my_tiles =
-      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
-  if (my_tiles == 0 || iter <= 0) return hipSuccess;
-  while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;  // pass groups must tile `iter`
-  const long long waves = my_tiles << pp_log2;
-  long long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+      f.tile_first >= g.tiles_total ? 0 : (g.tiles_total - f.tile_first + tile_stride - 1) / tile_stride;
+  if (my_tiles == 0 || f.passes <= 0) return hipSuccess;
+  const int pp_log2 = f.pp_log2 < 0 ? 0 : (f.pp_log2 > 6 ? 6 : f.pp_log2);
+  long long blocks = my_tiles << pp_log2;  // one wavefront per workgroup
   // blocks per tile row, for the XCD-aware order.  A partition (first, stride) whose
   // stride divides the row length owns tiles_x/stride tiles of every row -- columns of
   // tiles -- so its local slots still form rows and the same order applies.
   int bpr = 0;
-  if (xcd_rows && g.tiles_x % tile_stride == 0 && tile_first < tile_stride &&
-      ((long long)(g.tiles_x / tile_stride) << pp_log2) % kWavesPerBlock == 0) {
-    bpr = (int)(((long long)(g.tiles_x / tile_stride) << pp_log2) / kWavesPerBlock);
+  if (f.xcd_rows && g.tiles_x % tile_stride == 0 && f.tile_first < tile_stride) {
+    bpr = (int)((long long)(g.tiles_x / tile_stride) << pp_log2);
     const long long rows = (blocks + bpr - 1) / bpr;
     blocks = ((rows + 7) / 8) * 8 * bpr;  // pad to groups of 8 rows; surplus blocks exit at once
   }
-  const dim3 grid((unsigned)blocks, (unsigned)(iter >> pp_log2));
-  const dim3 block(64 * kWavesPerBlock);
-  const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
-  float4* st4 = reinterpret_cast<float4*>(staging);
-  if (accel.dist && accel.surf)
-    switch (min_waves) {
-      case 4: render_samples_kernel<true, 4><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
-      case 5: render_samples_kernel<true, 5><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
-      case 6: render_samples_kernel<true, 6><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
-      case 7: render_samples_kernel<true, 7><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
-      case 8: render_samples_kernel<true, 8><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
-      default: render_samples_kernel<true, 3><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, st4, n, tile_first, tile_stride, tpp, pp_log2, bpr, accel.oct_stride); break;
+  FrameArgs a;
+  a.vox = f.vox;
+  a.dist8 = f.accel.dist;
+  a.surf32 = f.accel.surf;
+  a.oct_stride = f.accel.oct_stride;
+  a.sdf = f.sdf;
+  a.mc_all = reinterpret_cast<const float4*>(f.mc_all);
+  a.opts_all = f.opts_all;
+  a.opts0 = f.opts0;
+  a.acc = reinterpret_cast<float4*>(f.acc);
+  a.argb = f.argb;
+  a.n = f.n; a.resx = f.resx; a.tile_first = f.tile_first; a.tile_stride = tile_stride;
+  a.tiles_per_part = tpp; a.pp_log2 = pp_log2; a.passes = f.passes; a.bpr = bpr;
+  a.accumulate = f.accumulate ? 1 : 0;
+  a.row_major = f.row_major ? 1 : 0;
+  const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  if (f.sdf) {
+    render_frame_kernel<false, 4, true><<<grid, block, 0, st>>>(a);
+  } else if (f.accel.dist && f.accel.surf) {
+    switch (f.min_waves) {
+      case 4: render_frame_kernel<true, 4><<<grid, block, 0, st>>>(a); break;
+      case 5: render_frame_kernel<true, 5><<<grid, block, 0, st>>>(a); break;
+      case 6: render_frame_kernel<true, 6><<<grid, block, 0, st>>>(a); break;
+      case 8: render_frame_kernel<true, 8><<<grid, block, 0, st>>>(a); break;
+      default: render_frame_kernel<true, 7><<<grid, block, 0, st>>>(a); break;
     }
-  else
-    render_samples_kernel<false, 3><<<grid, block, 0, st>>>(vox, nullptr, nullptr, mc4, d_opts_all, st4,
-                                                         n, tile_first, tile_stride, tpp, pp_log2, bpr, 0ull);
-  return hipGetLastError();
-}
-
-// QUALITY MODE (not reference-equivalent): same grid and lane layout, distance field instead
-// of the byte grid
-hipError_t launch_render_sdf(hipStream_t st, const float* d_sdf, const float* mc_all,
-                             const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
-                             int tile_first, int tile_stride, int pp_log2) {
-  const TileGeom g = tile_geom(resx, n);
-  if (tile_stride < 1) tile_stride = 1;
-  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
-  const long long my_tiles =
-      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
-  if (my_tiles == 0 || iter <= 0) return hipSuccess;
-  while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;
-  const long long blocks = ((my_tiles << pp_log2) + kWavesPerBlock - 1) / kWavesPerBlock;
-  const dim3 grid((unsigned)blocks, (unsigned)(iter >> pp_log2));
-  render_samples_kernel<false, 4, true><<<grid, dim3(64 * kWavesPerBlock), 0, st>>>(
-      nullptr, nullptr, nullptr, reinterpret_cast<const float4*>(mc_all), d_opts_all,
-      reinterpret_cast<float4*>(staging), n, tile_first, tile_stride, tpp, pp_log2, 0, 0ull, d_sdf);
-  return hipGetLastError();
-}
-
-hipError_t launch_render_split(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
-                               const RmOpts* d_opts_all, int resx, int iter, float* staging,
-                               float* hits, int n, int tile_first, int tile_stride, int waves_trace,
-                               int waves_light) {
-  const TileGeom g = tile_geom(resx, n);
-  if (tile_stride < 1) tile_stride = 1;
-  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
-  const long long my_tiles =
-      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
-  if (my_tiles == 0 || iter <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((my_tiles + kWavesPerBlock - 1) / kWavesPerBlock), (unsigned)iter);
-  const dim3 block(64 * kWavesPerBlock);
-  const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
-  float4* st4 = reinterpret_cast<float4*>(staging);
-  float4* h4 = reinterpret_cast<float4*>(hits);
-#define RM_T(W) trace_chain_kernel<W><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, h4, n, tile_first, tile_stride, tpp)
-#define RM_L(W) light_kernel<W><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, h4, st4, n, tile_first, tile_stride, tpp)
-  switch (waves_trace) {
-    case 4: RM_T(4); break;
-    case 6: RM_T(6); break;
-    default: RM_T(8); break;
+  } else {
+    render_frame_kernel<false, 3><<<grid, block, 0, st>>>(a);
   }
-  switch (waves_light) {
-    case 4: RM_L(4); break;
-    case 5: RM_L(5); break;
-    case 6: RM_L(6); break;
-    case 7: RM_L(7); break;
-    default: RM_L(8); break;
-  }
-#undef RM_T
-#undef RM_L
-  return hipGetLastError();
-}
-
-hipError_t launch_render_phases(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
-                                const RmOpts* d_opts_all, int resx, int iter, int levels,
-                                float* staging, void* work, int n, int tile_first, int tile_stride,
-                                int pp_log2) {
-  const TileGeom g = tile_geom(resx, n);
-  if (tile_stride < 1) tile_stride = 1;
-  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
-  const long long my_tiles =
-      tile_first >= g.tiles_total ? 0 : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
-  if (my_tiles == 0 || iter <= 0) return hipSuccess;
-  while (pp_log2 > 0 && (iter % (1 << pp_log2)) != 0) pp_log2--;
-  const long long waves = my_tiles << pp_log2;
-  const unsigned bx = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-  const unsigned by = (unsigned)(iter >> pp_log2);
-  const dim3 block(64 * kWavesPerBlock);
-  const size_t samples = (size_t)iter * tpp * 64;
-  float4* hits = static_cast<float4*>(work);
-  float2* rays = reinterpret_cast<float2*>(hits + samples * levels * 2);
-  const float4* mc4 = reinterpret_cast<const float4*>(mc_all);
-  float4* st4 = reinterpret_cast<float4*>(staging);
-  phase_kernel<1><<<dim3(bx, by, 1), block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, hits, rays,
-                                                      st4, n, tile_first, tile_stride, tpp, pp_log2, iter);
-  phase_kernel<2><<<dim3(bx, by, (unsigned)levels), block, 0, st>>>(vox, accel.dist, accel.surf, mc4,
-                                                                     d_opts_all, hits, rays, st4, n,
-                                                                     tile_first, tile_stride, tpp,
-                                                                     pp_log2, iter);
-  phase_kernel<3><<<dim3(bx, by, 1), block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts_all, hits, rays,
-                                                      st4, n, tile_first, tile_stride, tpp, pp_log2, iter);
-  return hipGetLastError();
-}
-size_t phases_workspace_bytes(size_t samples, int levels) { return samples * levels * (32 + 8) + 256; }
-
-hipError_t launch_render_wave(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc_all,
-                              const RmOpts* d_opts_all, int resx, int iter, float* staging, int n,
-                              int tile_first, int tile_stride, unsigned int* d_queue, int blocks,
-                              int min_waves, int wait_lanes) {
-  const TileGeom g = tile_geom(resx, n);
-  if (tile_stride < 1) tile_stride = 1;
-  WaveArgs a;
-  a.vox = vox;
-  a.dist8 = accel.dist;
-  a.surf32 = accel.surf;
-  a.mc_all = reinterpret_cast<const float4*>(mc_all);
-  a.opts_all = d_opts_all;
-  a.staging = reinterpret_cast<float4*>(staging);
-  a.queue = d_queue;
-  a.n = n;
-  a.iter = iter;
-  a.tile_first = tile_first;
-  a.tile_stride = tile_stride;
-  a.tiles_per_part = tiles_per_part(g.tiles_total, tile_stride);
-  a.my_tiles = tile_first >= g.tiles_total
-                   ? 0
-                   : (g.tiles_total - tile_first + tile_stride - 1) / tile_stride;
-  a.resx = resx;
-  a.wait_lanes = wait_lanes;
-  if (a.my_tiles == 0 || iter <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(unsigned int), st);
-  if (e != hipSuccess) return e;
-  const int waves_needed = (a.my_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > waves_needed) blocks = waves_needed;
-  switch (min_waves) {
-    case 2: render_wave_kernel<2><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
-    case 3: render_wave_kernel<3><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
-    case 5: render_wave_kernel<5><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
-    default: render_wave_kernel<4><<<blocks, 64 * kWavesPerBlock, 0, st>>>(a); break;
-  }
-  return hipGetLastError();
-}
-
-int wave_kernel_blocks_per_cu(int min_waves) {
-  int nb = 0;
-  hipError_t e;
-  switch (min_waves) {
-    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<2>, 64 * kWavesPerBlock, 0); break;
-    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<3>, 64 * kWavesPerBlock, 0); break;
-    case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<5>, 64 * kWavesPerBlock, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_wave_kernel<4>, 64 * kWavesPerBlock, 0); break;
-  }
-  if (e != hipSuccess || nb < 1) nb = 1;
-  return nb;
-}
-
-hipError_t launch_blend(hipStream_t st, const float* staging, const RmOpts* d_opts_all, int iter,
-                        long long count, float* tiles) {
-  if (count <= 0) return hipSuccess;
-  long long blocks = (count + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  blend_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(staging), d_opts_all,
-                                                 iter, count, reinterpret_cast<float4*>(tiles));
   return hipGetLastError();
 }
 

@@ -4,19 +4,14 @@
 // replaces is cited next to it).  Scalar float32 throughout, every expression
 // in the reference's evaluation order, no FMA contraction (see rm_detmath.hpp).
 //
-// This header holds the "straight" formulation: one lane owns one sample from
-// camera ray to final colour.  rm_kernels.hip wraps it in the RenderImage-
-// equivalent kernel; the wave-scheduled variant lives in rm_wave.hpp and is
-// checked against this one.
+// One lane owns one sample from camera ray to final colour (shade()); in the frame kernel
+// the AO probes and shadow rays of a wavefront's hits are traced by all its lanes
+// (shade_wave()).  rm_kernels.hip wraps both in the kernels.
 #pragma once
 #include "rm_detmath.hpp"
 #include "rm_opts.h"
 
 namespace rmk {
-
-#ifndef RM_BRICKS
-#define RM_BRICKS 0  // dist8 / oct8 in 8x4x4-cell bricks (A/B switch; host and device must agree)
-#endif
 
 struct v3 { float x, y, z; };
 RM_DEV v3 V(float x, float y, float z) { return v3{x, y, z}; }
@@ -62,8 +57,7 @@ struct Scene {
   const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
 };
 
-// ---- leaf routines shared by the straight (Tracer) and wave-scheduled
-// (rm_wave.hpp) forms; `o` points at the option record in device memory ----
+// ---- leaf routines; `o` points at the option record in device memory ----
 
 // materials[id] by byte offset, defined for every id (see oracle/rm_restate.c);
 // *oob is set when the index falls outside the record (undefined in the reference)
@@ -155,29 +149,15 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
   // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
   // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
-#if RM_BRICKS
-  // tables are stored in 8x4x4-cell bricks = one 128-byte line each (rm_accel.hip): lanes
-  // of a wavefront and consecutive fetches of a ray then share lines far more often
-  const unsigned nbx = ((unsigned)o.voxelRes[0] + 7u) >> 3, nby = ((unsigned)o.voxelRes[1] + 3u) >> 2;
-  const unsigned brick = __umul24(__umul24((unsigned)qz >> 2, nby) + ((unsigned)qy >> 2), nbx) + ((unsigned)qx >> 3);
-  const unsigned within = ((((unsigned)qz & 3u) << 2 | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
-  const int d = dist8[((brick << 7) | within) + table_off];
-#else
   const unsigned cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
                                  (unsigned)o.voxelRes[0]) + (unsigned)qx;
   const int d = dist8[cell + table_off];
-#endif
   if (dhist) {  // stats build only
     dhist[d < 4 ? d : (d < 8 ? 4 : 5)]++;
     dhist[6] = (unsigned)d;
   }
   if (d == 0) {
-#if RM_BRICKS
-    *cell_out = (int)(__umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
-                               (unsigned)o.voxelRes[0]) + (unsigned)qx);  // surf32 stays row-major
-#else
     *cell_out = (int)cell;
-#endif
     return 1;
   }
   // (the floor argument above needs p >= 0; tiny p also means tiny binades)
@@ -907,206 +887,6 @@ struct Tracer {
     return normalize(right * vx + upv * vy + fwd);
   }
 
-  // ---- the same sample split in two at its only long-lived values ----
-  // Register pressure of shade() peaks inside a shadow march nested in the
-  // lighting of a reflection nested in the primary shading (~140 VGPRs, 3 waves
-  // per SIMD; or 64 VGPRs + heavy scratch traffic).  The primary march and the
-  // reflection marches do not depend on any lighting result (bounce k+1 needs only
-  // the hit of bounce k, renderer.cl:433-437), so they can run first and leave
-  // 32 B per hit in HBM; the lighting pass then never holds a march of its own
-  // caller.  Both halves evaluate exactly the expressions of sample_colour().
-  // hits: [level][samples] x 2 float4 = (pos, distance) (normal, objectID bits).
-  RM_DEV void trace_chain(int id, float4* __restrict__ hits, size_t samples, size_t sidx) {
-    const RmOpts& o = *sc.o;
-    const Sample s = sample_init(id);
-    const v3 rdir = camera_dir(s);
-    Hit h{};
-    march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
-    hits[sidx * 2] = make_float4(h.pos.x, h.pos.y, h.pos.z, h.distance);
-    hits[sidx * 2 + 1] = make_float4(h.normal.x, h.normal.y, h.normal.z, __int_as_float(h.objectID));
-    // the record after the last traced level says "no such bounce" (objectID -1)
-    float4* const nxt = hits + (samples + sidx) * 2 + 1;
-    if (o.reflectIter > 0) *nxt = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-    if (h.distance >= o.maxDist) return;
-    const Material m = material(h.objectID);
-    if (!(m.r0 > 0.0f && o.reflectIter > 0)) return;
-    const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
-    Hit rh{};
-    rh.pos = h.pos;
-    rh.normal = mads(s.mcNormal, k, h.normal);
-    v3 dir = rdir;
-    for (int i = 0; i < o.reflectIter; i++) {
-      dir = reflect(dir, rh.normal);
-      const v3 from = mads(dir, 0.0075f, rh.pos);
-      march(from, dir, rh, o.maxDist, o.maxIter, false);
-      float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
-      hk[0] = make_float4(rh.pos.x, rh.pos.y, rh.pos.z, rh.distance);
-      hk[1] = make_float4(rh.normal.x, rh.normal.y, rh.normal.z, __int_as_float(rh.objectID));
-      if (i + 1 < o.reflectIter) hk[samples * 2 + 1] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-      if (rh.objectID < 0) break;
-      if ((double)material(rh.objectID).r0 < 0.001) break;
-    }
-  }
-  RM_DEV v3 shade_from_hits(int id, const float4* __restrict__ hits, size_t samples, size_t sidx) {
-    const RmOpts& o = *sc.o;
-    const Sample s = sample_init(id);
-    const v3 rdir = camera_dir(s);
-    const float4 ha = hits[sidx * 2], hb = hits[sidx * 2 + 1];
-    const float hdist = ha.w;
-    v3 col;
-    if (hdist >= o.maxDist) {
-      col = sky(rdir);
-    } else {
-      const v3 hpos = V(ha.x, ha.y, ha.z);
-      const Material m = material(__float_as_int(hb.w));
-      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
-      const v3 norm = mads(s.mcNormal, k, V(hb.x, hb.y, hb.z));
-      v3 refl = V(0.f, 0.f, 0.f);
-      if (m.r0 > 0.0f && o.reflectIter > 0) {
-        v3 lpos = hpos, lnrm = norm, dir = rdir;
-        for (int i = 0; i < o.reflectIter; i++) {
-          dir = reflect(dir, lnrm);
-          const v3 from = mads(dir, 0.0075f, lpos);
-          const float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
-          const float4 ka = hk[0], kb = hk[1];
-          const int obj = __float_as_int(kb.w);
-          lpos = V(ka.x, ka.y, ka.z);
-          lnrm = V(kb.x, kb.y, kb.z);
-          v3 bc;
-          if (obj < 0) {
-            bc = sky(dir);
-          } else {
-            bc = lighting(s, dir, lpos, material(obj), lnrm, sky(reflect(dir, lnrm)));
-          }
-          refl = refl + atmosphere(s, from, dir, ka.w, bc);
-          if (obj < 0) break;
-          if ((double)material(obj).r0 < 0.001) break;
-        }
-      } else {
-        refl = sky(reflect(rdir, norm));
-      }
-      col = lighting(s, rdir, hpos, m, norm, refl);
-    }
-    return atmosphere(s, s.eye, rdir, hdist, col) * o.exposure;
-  }
-
-  // ---- three-phase form: (1) trace_chain, (2) the RAYS of each shaded point --
-  // its AO loop and one shadow march per light -- reduced to one float and one bit
-  // per light, (3) all shading arithmetic from those.  No phase holds another
-  // phase's state, so each compiles to <= 64 VGPRs without scratch traffic.
-  // Per-sample seeds without the camera (phase 2 needs no ray direction).
-  RM_DEV Sample sample_seeds(int id) {
-    const RmOpts& o = *sc.o;
-    Sample s;
-    s.time = time_;
-    const int resx = o.resolution[0];
-    const float4 mcPos = table((uint32_t)id * 17u + rmd::f2u(time_ * 3141.3862f));
-    s.px = (float)(id % resx) + mcPos.z;
-    s.py = (float)(id / resx) + mcPos.w;
-    s.mcNormal = V(0.f, 0.f, 0.f);
-    s.eye = s.mcNormal;
-    return s;
-  }
-  RM_DEV v3 sample_mc_normal(int id) {  // renderer.cl:472
-    const float4 t = table((uint32_t)id * 37u + rmd::f2u(time_ * 1859.1467f));
-    return normalize(V(t.x, t.y, t.z));
-  }
-  // phase 2: renderer.cl:327-346 and the shadow() calls of :361-369 for one point.
-  // -> (ao, bit i = shadow factor of light i, which is 0 or 1: renderer.cl:300)
-  RM_DEV float2 point_rays(const Sample& s, v3 pos, v3 normal) {
-    const RmOpts& o = *sc.o;
-    const float ao = occlusion(s, pos, normal);
-    unsigned bits = 0;
-    const int nl = o.numLights;
-    for (int i = 0; i < nl; i++) {
-      const v3 dl = light_at(s, i) - pos;
-      const float d2 = dot(dl, dl);
-      const float att = 1.0f / d2;
-      if (att > o.minLightAtt) {
-        const v3 ldir = normalize(dl);
-        const float sh = shadow_term(mads(ldir, o.shadowBias, pos), ldir,
-                                     rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist));
-        if (sh > 0.0f) bits |= 1u << i;
-      }
-    }
-    return make_float2(ao, __uint_as_float(bits));
-  }
-  // phase 3: lighting() with the rays' outcomes supplied (same arithmetic, same order)
-  RM_DEV v3 lighting_math(const Sample& s, v3 raydir, v3 hitpos, const Material& m, v3 normal,
-                          v3 reflectCol, float ao, unsigned bits) {
-    const RmOpts& o = *sc.o;
-    v3 diff = sky(normal) * ao;
-    v3 spec = reflectCol * ao;
-    v3 out = V(0.f, 0.f, 0.f);
-    const int nl = o.numLights;
-    for (int i = 0; i < nl; i++) {
-      const v3 dl = light_at(s, i) - hitpos;
-      const float d2 = dot(dl, dl);
-      const float att = 1.0f / d2;
-      if (att > o.minLightAtt) {
-        const v3 ldir = normalize(dl);
-        const float sh = (bits >> i) & 1u ? 1.0f : 0.0f;
-        if (sh > 0.0f) {
-          const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-          diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
-          spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
-        }
-      }
-      diff = diff * m.albedo;
-      out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
-    }
-    const float fl = (float)nl;
-    return V(out.x / fl, out.y / fl, out.z / fl);
-  }
-  // phase 3 for one sample; rays: [level][samples] float2 from point_rays
-  RM_DEV v3 shade_from_rays(int id, const float4* __restrict__ hits, const float2* __restrict__ rays,
-                            size_t samples, size_t sidx) {
-    const RmOpts& o = *sc.o;
-    const Sample s = sample_init(id);
-    const v3 rdir = camera_dir(s);
-    const float4 ha = hits[sidx * 2], hb = hits[sidx * 2 + 1];
-    const float hdist = ha.w;
-    v3 col;
-    if (hdist >= o.maxDist) {
-      col = sky(rdir);
-    } else {
-      const v3 hpos = V(ha.x, ha.y, ha.z);
-      const Material m = material(__float_as_int(hb.w));
-      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
-      const v3 norm = mads(s.mcNormal, k, V(hb.x, hb.y, hb.z));
-      v3 refl = V(0.f, 0.f, 0.f);
-      if (m.r0 > 0.0f && o.reflectIter > 0) {
-        v3 lpos = hpos, lnrm = norm, dir = rdir;
-        for (int i = 0; i < o.reflectIter; i++) {
-          dir = reflect(dir, lnrm);
-          const v3 from = mads(dir, 0.0075f, lpos);
-          const float4* hk = hits + ((size_t)(1 + i) * samples + sidx) * 2;
-          const float4 ka = hk[0], kb = hk[1];
-          const int obj = __float_as_int(kb.w);
-          lpos = V(ka.x, ka.y, ka.z);
-          lnrm = V(kb.x, kb.y, kb.z);
-          v3 bc;
-          if (obj < 0) {
-            bc = sky(dir);
-          } else {
-            const float2 rr = rays[(size_t)(1 + i) * samples + sidx];
-            bc = lighting_math(s, dir, lpos, material(obj), lnrm, sky(reflect(dir, lnrm)), rr.x,
-                               __float_as_uint(rr.y));
-          }
-          refl = refl + atmosphere(s, from, dir, ka.w, bc);
-          if (obj < 0) break;
-          if ((double)material(obj).r0 < 0.001) break;
-        }
-      } else {
-        refl = sky(reflect(rdir, norm));
-      }
-      const float2 r0 = rays[sidx];
-      col = lighting_math(s, rdir, hpos, m, norm, refl, r0.x, __float_as_uint(r0.y));
-    }
-    return atmosphere(s, s.eye, rdir, hdist, col) * o.exposure;
-  }
-
-
   // =====================================================================================
   // The same sample with its secondary rays SHARED by the wavefront.
   //
@@ -1328,19 +1108,21 @@ struct Tracer {
     return res;
   }
 
-  // sample_colour() with wave-uniform control flow around the shared phases
-  RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir) {
+  // sample_colour() with wave-uniform control flow around the shared phases.  A lane that is
+  // not `live` owns no sample in this turn (its pass lies beyond the frame's last): it traces
+  // nothing of its own but still deals with the other lanes' secondary rays.
+  RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
     const RmOpts& o = *sc.o;
     Hit h{};
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_p0 = ws_now();
 #endif
-    march(ro, rdir, h, o.maxDist, o.maxIter, true);
+    if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_p1 = ws_now();
     if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
 #endif
-    const bool hit = !(h.distance >= o.maxDist);
+    const bool hit = live && !(h.distance >= o.maxDist);
     Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
     v3 norm = V(0.f, 0.f, 0.f);
     if (hit) {
@@ -1397,11 +1179,11 @@ struct Tracer {
 
   // shade() through the wave-shared path; every lane of the wavefront that has a pixel
   // must call it (lanes without one have left the kernel), lds = kWaveLdsFloats floats
-  RM_DEV v3 shade_wave(int id, float* lds) {
+  RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
     lds_ = lds;
     const Sample s = sample_init(id);
     const v3 rdir = camera_dir(s);
-    return sample_colour_wave(s, s.eye, rdir) * sc.o->exposure;
+    return sample_colour_wave(s, s.eye, rdir, live) * sc.o->exposure;
   }
 
   // colour * exposure of work-item `id` (the value RenderImage blends in, renderer.cl:491)

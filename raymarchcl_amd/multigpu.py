@@ -13,6 +13,8 @@ any partition of the image gives bit-identical pixels.  Layout:
 * ONE collective per frame: gather of the tile-major accumulators to rank 0
   (torch.distributed -> RCCL over xGMI: point-to-point sends into the root, all
   links concurrently); the root un-permutes + tonemaps (rm_resolve_device).
+* with ONE rank there is no partition: the frame kernel writes the row-major image and the
+  ARGB words itself (rm_frame_device_full), one launch per frame.
 
 The volume, the scatter tables and the option records are replicated.
 """
@@ -87,12 +89,14 @@ def gather_tiles(local_tiles, rank, world, dst=0, group=None):
 
 
 class _Slot:
-    """What one frame in flight owns: a HIP stream, a library context bound to it (its
-    staging buffers and derived structures), the tile accumulators and the outputs."""
+    """What one frame in flight owns: a HIP stream, a library context bound to it, the tile
+    accumulators (partitioned frames) and the outputs.  The volume and the tables derived from
+    it belong to the first slot's context; the others share them (rm_share_volume)."""
 
-    def __init__(self, torch, _native, dev, stream, tpp, n, root, want_pixels, want_argb):
+    def __init__(self, torch, _native, dev, stream, tpp, n, root, want_pixels, want_argb, world):
         self.stream = stream
-        self.d_tiles = torch.zeros(tpp * TILE_PIXELS * 4, dtype=torch.float32, device=dev)
+        self.d_tiles = (torch.zeros(tpp * TILE_PIXELS * 4, dtype=torch.float32, device=dev)
+                        if world > 1 else None)
         self.d_pixels = torch.empty(4 * n, dtype=torch.float32, device=dev) if (root and want_pixels) else None
         self.d_argb = torch.empty(n, dtype=torch.int32, device=dev) if (root and want_argb) else None
         self.ctx = _native.Context(dev.index or 0)
@@ -140,8 +144,11 @@ class FrameRenderer:
             # few hardware queues round-robin, so these land on distinct queues, whereas the
             # caller's stream may share one with them (two slots on one queue do not overlap).
             stream = torch.cuda.current_stream(dev) if nslots == 1 else torch.cuda.Stream(dev)
-            slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb)
-            slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
+            slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb, world)
+            if i == 0:
+                slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
+            else:
+                slot.ctx.share_volume(self.slots[0].ctx)
             slot.ctx.check_device_opts(self.d_opts.data_ptr(), self.iters, self.n, self.width)
             self.slots.append(slot)
         self.frame = 0
@@ -157,6 +164,12 @@ class FrameRenderer:
         slot = self.slots[self.frame % len(self.slots)]
         self.frame += 1
         with torch.cuda.stream(slot.stream):
+            if self.world == 1:  # the whole frame incl. tonemap is one kernel launch
+                slot.ctx.frame_device_full(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
+                                           self.width,
+                                           slot.d_pixels.data_ptr() if slot.d_pixels is not None else None,
+                                           slot.d_argb.data_ptr() if slot.d_argb is not None else None)
+                return slot.d_pixels, slot.d_argb
             slot.ctx.frame_device(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
                                   self.width, slot.d_tiles.data_ptr(), self.rank, self.world)
             allt = self._gather(slot)

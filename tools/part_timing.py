@@ -39,15 +39,18 @@ def main():
         times = []
         for rank in range(world):
             fr = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world,
-                                        device=dev, want_pixels=False, want_argb=False,
+                                        device=dev, want_pixels=True, want_argb=False,
                                         frames_in_flight=args.frames_in_flight)
 
+            tiles = [torch.zeros(fr.tpp * 256, dtype=torch.float32, device=dev) for _ in fr.slots]
+
             def share():
-                slot = fr.slots[fr.frame % len(fr.slots)]
+                k = fr.frame % len(fr.slots)
+                slot = fr.slots[k]
                 fr.frame += 1
                 with torch.cuda.stream(slot.stream):
                     slot.ctx.frame_device(fr.d_opts.data_ptr(), fr.d_mc.data_ptr(), fr.iters, fr.n,
-                                          fr.width, slot.d_tiles.data_ptr(), rank, world)
+                                          fr.width, tiles[k].data_ptr(), rank, world)
 
             for _ in range(len(fr.slots)):
                 share()

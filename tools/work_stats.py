@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Debug helper: render one frame of a bench workload with the RM_WORK_STATS build
 (hipcc <flags of _native.HIPCC_FLAGS> -DRM_WORK_STATS -o raymarchcl_amd/libraymarch_hip_stats.so) and print what
-render_samples_kernel executed per sample (marches, turns, filtered turns, walks,
+render_frame_kernel executed per sample (marches, turns, filtered turns, walks,
 dist8 fetches, samples advanced, AO loops).
 
     python tools/work_stats.py [c2] [--clock]
