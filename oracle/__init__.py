@@ -104,14 +104,22 @@ def restate_lib():
     return _restate
 
 
+def _ref_name(fma):
+    """fma: False = the oracle build, True = FMA-contracted, "libm" = exp/exp2/pow from libm."""
+    return {False: "libref_oracle.so", True: "libref_oracle_fma.so", "libm": "libref_oracle_libm.so"}[fma]
+
+
 def have_ref(fma=False):
-    return os.path.exists(os.path.join(HERE, "_ref", "libref_oracle_fma.so" if fma else "libref_oracle.so"))
+    return os.path.exists(os.path.join(HERE, "_ref", _ref_name(fma)))
 
 
 def ref_lib(fma=False):
     if fma not in _refs:
-        path = os.path.join(HERE, "_ref", "libref_oracle_fma.so" if fma else "libref_oracle.so")
+        path = os.path.join(HERE, "_ref", _ref_name(fma))
         lib = ctypes.CDLL(path)
+        lib.ref_shim_eval.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+        lib.ref_shim_eval.restype = ctypes.c_int
         lib.ref_render_image.argtypes = [_u8p, _f32p, ctypes.c_void_p, _f32p, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int]
         lib.ref_render_image.restype = None
@@ -228,6 +236,25 @@ def ref_render_image_mt(vox, mc, opts, pixels, threads, n=None, id0=0, id1=None,
     ref_lib(fma).ref_render_image_mt(_ptr(vox, _u8p), _ptr(mc, _f32p), ob, _ptr(pixels, _f32p), n,
                                      id0, id1, int(threads))
     return pixels
+
+
+SHIM_OPS = {"convert_float3": 0, "convert_int3_sat": 1, "dot": 2, "exp": 3, "exp2": 4, "pow": 5, "fabs": 6,
+            "sqrt": 7, "mad": 8, "mad3": 9, "max": 10, "max3": 11, "min": 12, "min3": 13, "mix3": 14,
+            "mix3s": 15, "step": 16, "clamp": 17, "cross": 18, "length": 19, "normalize": 20,
+            "get_global_id": 21}
+
+
+def shim_eval(name, a, b=None, c=None, out_shape=None, out_dtype=np.float32, fma=False):
+    """Call built-in ``name`` of the shim the reference object is linked against (test hook)."""
+    a = np.ascontiguousarray(a)
+    count = a.shape[0]
+    out = np.zeros(out_shape if out_shape is not None else a.shape, dtype=out_dtype)
+    args = [np.ascontiguousarray(x, dtype=np.float32) if x is not None else None for x in (b, c)]
+    rc = ref_lib(fma).ref_shim_eval(SHIM_OPS[name], count, a.ctypes.data,
+                                    args[0].ctypes.data if args[0] is not None else None,
+                                    args[1].ctypes.data if args[1] is not None else None, out.ctypes.data)
+    assert rc == 0
+    return out
 
 
 def ref_tonemap_image(pixels, opts, n=None, fma=False):

@@ -142,7 +142,9 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
   return 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
 }
 
-template <bool ACCEL, int MINW, bool SDFM = false>
+// MULTI = the launch holds more passes than a wavefront does (the loop over groups of passes
+// exists only then: a single group keeps nothing alive across the body of a sample)
+template <bool ACCEL, int MINW, bool SDFM, bool MULTI>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   using Tr = rmk::Tracer<false, ACCEL, SDFM>;
   const int pp_log2 = a.pp_log2;
@@ -190,9 +192,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   unsigned long long ws_acc[64];
   for (int k = 0; k < 64; k++) ws_acc[k] = 0ull;
 #endif
-  for (int c0 = 0; c0 < a.passes; c0 += pp) {
+  for (int c0 = 0; c0 < (MULTI ? a.passes : 1); c0 += pp) {
     const int pass = c0 + pl;
+#ifdef RM_AB_NOLIVE
+    const bool live = true;  // (A/B only: valid when passes is a multiple of pp)
+#else
     const bool live = pass < a.passes;
+#endif
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
     rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
     Tr tr(sc);
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
     }
 #ifdef RM_PHASE_CLOCK
     for (int k = 0; k < 5; k++) ws_acc[32 + k] += tr.ws_clk[k];
+    for (int k = 5; k < 13; k++) ws_acc[56 + k - 5] += tr.ws_clk[k];
     if (tr.ws_now()) ws_acc[37] += 1ull;
 #endif
 #ifdef RM_WORK_STATS
@@ -364,6 +371,10 @@ void dump_work_stats() {
     fprintf(stderr, "[phase clock] wave time by phase (shader clock ticks per wave): primary march %.0f, reflection "
                     "marches %.0f, AO phases %.0f, shadow phases %.0f, shading arithmetic %.0f\n",
             h[32] / waves, h[33] / waves, h[34] / waves, h[35] / waves, h[36] / waves);
+    fprintf(stderr, "[phase clock]   inside those: walk loops %.0f, estimate set-up %.0f, hit evaluation %.0f, filtered-turn "
+                    "loops %.0f, march set-up %.0f, AO task set-up %.0f, shadow task set-up %.0f; sample + camera %.0f\n",
+            h[56] / waves, (h[57] - h[56] - h[58]) / waves, h[58] / waves, h[59] / waves, h[60] / waves, h[61] / waves,
+            h[62] / waves, h[63] / waves);
   }
 #endif
 #if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
@@ -444,19 +455,26 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.accumulate = f.accumulate ? 1 : 0;
   a.row_major = f.row_major ? 1 : 0;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  const bool multi = f.passes > (1 << pp_log2);
+#define RM_FRAME(A, W, S)                                                    \
+  do {                                                                       \
+    if (multi) render_frame_kernel<A, W, S, true><<<grid, block, 0, st>>>(a); \
+    else render_frame_kernel<A, W, S, false><<<grid, block, 0, st>>>(a);      \
+  } while (0)
   if (f.sdf) {
-    render_frame_kernel<false, 4, true><<<grid, block, 0, st>>>(a);
+    RM_FRAME(false, 4, true);
   } else if (f.accel.dist && f.accel.surf) {
     switch (f.min_waves) {
-      case 4: render_frame_kernel<true, 4><<<grid, block, 0, st>>>(a); break;
-      case 5: render_frame_kernel<true, 5><<<grid, block, 0, st>>>(a); break;
-      case 6: render_frame_kernel<true, 6><<<grid, block, 0, st>>>(a); break;
-      case 8: render_frame_kernel<true, 8><<<grid, block, 0, st>>>(a); break;
-      default: render_frame_kernel<true, 7><<<grid, block, 0, st>>>(a); break;
+      case 4: RM_FRAME(true, 4, false); break;
+      case 5: RM_FRAME(true, 5, false); break;
+      case 6: RM_FRAME(true, 6, false); break;
+      case 8: RM_FRAME(true, 8, false); break;
+      default: RM_FRAME(true, 7, false); break;
     }
   } else {
-    render_frame_kernel<false, 3><<<grid, block, 0, st>>>(a);
+    RM_FRAME(false, 3, false);
   }
+#undef RM_FRAME
   return hipGetLastError();
 }
 

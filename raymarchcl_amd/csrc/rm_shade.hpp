@@ -192,6 +192,13 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 // 11.10 / 11.16 ms with the first / second / both: register pressure); with the shared
 // phases 8.87 ms without, 8.78 / 8.89 / 8.73 ms.  Switchable for re-measuring
 // (tools/ab_build.py).
+// A/B: lighting_wave() out of line (one copy, a call boundary as the spill point) -- measured
+// equal to inlining on the 5.3 ms build
+#ifdef RM_NOINLINE_LIGHT
+#define RM_DEV_LIGHT __device__ __attribute__((noinline))
+#else
+#define RM_DEV_LIGHT RM_DEV
+#endif
 #ifndef RM_FASTDIV
 #define RM_FASTDIV 1      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
 #endif
@@ -244,11 +251,18 @@ struct Tracer {
   // debug build only (-DRM_PHASE_CLOCK, no other instrumentation): wave time per phase of
   // shade_wave in shader clock ticks, charged to the wave's first active lane:
   // 0 primary march, 1 reflection marches, 2 AO phases, 3 shadow phases, 4 shading arithmetic
-  unsigned long long ws_clk[5] = {0, 0, 0, 0, 0};
+  // 5 walk loops, 6 estimate set-up (scene_distance up to its walk), 7 hit evaluation, 8 filtered-turn
+  // loops, 9 march set-up (filter, limits), 10 AO task set-up, 11 shadow task set-up, 12 sample + camera
+  unsigned long long ws_clk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   RM_DEV unsigned long long ws_now() {
     const unsigned long long act = __ballot(1);
     return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? (unsigned long long)clock64() : 0ull;
   }
+#define RM_CLK_T(v) const unsigned long long v = ws_now()
+#define RM_CLK_ADD(k, a, b) do { if ((a) && (b)) ws_clk[k] += (b) - (a); } while (0)
+#else
+#define RM_CLK_T(v) ((void)0)
+#define RM_CLK_ADD(k, a, b) ((void)0)
 #endif
   RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {}
   RM_DEV void set_pass(const float4* table_of_pass, float time_of_pass) {
@@ -425,6 +439,7 @@ struct Tracer {
       return;
     }
     if (COUNT) cnt.dts_calls++;
+    RM_CLK_T(ck_e0);
     const float h = rpos.y + o.groundY;
     float rd, rc;
     if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
@@ -476,6 +491,7 @@ struct Tracer {
         // others and all hits are then evaluated together (inside the loop the compiler
         // runs the hit code once per trip in which any lane finishes)
         int cell = 0, r;
+        RM_CLK_T(ck_w0);
 #ifdef RM_WORK_STATS
         const int ws_steps0 = steps;
         int ws_klast = 0;
@@ -498,6 +514,8 @@ struct Tracer {
           if (ws_dhist[6] <= 1u && r == 0) ws_klast = ws_steps0 - steps;
 #endif
         } while (r == 0);
+        RM_CLK_T(ck_w1);
+        RM_CLK_ADD(5, ck_w0, ck_w1);
 #ifdef RM_WORK_STATS
         if (r == 1) ws_adds_hit += (unsigned)(ws_steps0 - steps);
         else {
@@ -515,6 +533,8 @@ struct Tracer {
           const float d = length(rpos - hit) - o.voxelSize;
           if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }
         }
+        RM_CLK_T(ck_w2);
+        RM_CLK_ADD(7, ck_w1, ck_w2);
       } else
       while (--steps >= 0) {
         const int qx = rmd::convert_int_sat(p.x * frx);
@@ -536,6 +556,8 @@ struct Tracer {
     }
     dist = rd;
     code = rc;
+    RM_CLK_T(ck_e1);
+    RM_CLK_ADD(6, ck_e0, ck_e1);  // (includes 5 and 7: subtracted when printed)
   }
 
   struct Hit { v3 pos, normal; float distance; int objectID; };
@@ -613,6 +635,7 @@ struct Tracer {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
     RM_WS(ws_rays++);
+    RM_CLK_T(ck_m0);
     float dist = o.startDist;
     // (the filter reasons about the clip box of the byte grid: off for the counting variant,
     //  which must run the plain algorithm, and for the quality mode, whose field extends
@@ -644,9 +667,12 @@ struct Tracer {
     const float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
+    RM_CLK_T(ck_m1);
+    RM_CLK_ADD(9, ck_m0, ck_m1);
     for (;;) {
       float g = 0.0f;
       why = 2;
+      RM_CLK_T(ck_f0);
       if (maxSteps > 0) {
         // one exit: a turn either continues (filtered, not converged, turns left) or not
         bool nw, go;
@@ -666,6 +692,8 @@ struct Tracer {
         why = go ? 2 : (nw ? 3 : 1);
         if (nw) last_kind = 0;
       }
+      RM_CLK_T(ck_f1);
+      RM_CLK_ADD(8, ck_f0, ck_f1);
       if (why != 1) break;
       float sd;
       RM_WS(wv_est += wave_slots());
@@ -714,23 +742,30 @@ struct Tracer {
 
   struct Sample { v3 eye; v3 mcNormal; float px, py; float time; };
 
-  // jittered light position: renderer.cl:263-269
-  RM_DEV v3 light_at(const Sample& s, int i) {
+  // jittered light position: renderer.cl:263-269.  The table index depends on the sample only
+  // (one jitter for all lights and all shading points of a sample): light_seed().
+  RM_DEV static uint32_t light_seed(const Sample& s) {
+    return rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
+  }
+  RM_DEV v3 light_at_seed(uint32_t seed, int i) {
     const RmOpts& o = *sc.o;
-    const uint32_t seed = rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
     const float4 r = table(seed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
+  RM_DEV v3 light_at(const Sample& s, int i) { return light_at_seed(light_seed(s), i); }
   RM_DEV v3 reflect(v3 v, v3 n) { return reflect_of(v, n); }
   // fog + flares: renderer.cl:275-290
   RM_DEV v3 atmosphere(const Sample& s, v3 ro, v3 rdir, float dist, v3 col) {
+    return atmosphere_seed(light_seed(s), ro, rdir, dist, col);
+  }
+  RM_DEV v3 atmosphere_seed(uint32_t lseed, v3 ro, v3 rdir, float dist, v3 col) {
     const RmOpts& o = *sc.o;
     const float fa = 1.0f - rmd::exp_det(dist * dist * -o.fogPow);
     const v3 sk = sky(rdir);
     col = V((sk.x - col.x) * fa + col.x, (sk.y - col.y) * fa + col.y, (sk.z - col.z) * fa + col.z);
     const int nl = o.numLights;
     for (int i = 0; i < nl; i++) {
-      v3 lp = light_at(s, i);
+      v3 lp = light_at_seed(lseed, i);
       const float d = rmd::clamp_cl(dot(lp - ro, rdir), 0.0f, dist);
       lp = mads(rdir, d, ro - lp);
       const float k = o.flareAmp / dot(lp, lp);
@@ -931,14 +966,19 @@ struct Tracer {
   }
 
   // occlusion() for all lanes of the wavefront at once; `active` lanes own a hit
-  RM_DEV float occlusion_wave(bool active, const Sample& s, v3 pos, v3 normal) {
+  // (s.time of the reference's seed is this lane's pass time: time_)
+  RM_DEV float occlusion_wave(bool active, v3 pos, v3 normal) {
     const RmOpts& o = *sc.o;
     const int np = o.aoIter + 1;
     const Deal dl = deal(active);
     if (dl.owners == 0) return 1.0f;
-    if (np > kWaveLdsRes) return active ? occlusion(s, pos, normal) : 1.0f;  // (uniform) too many probes to post
+    if (np > kWaveLdsRes) {  // (uniform) too many probes to post: every owner traces its own
+      Sample st{};
+      st.time = time_;
+      return active ? occlusion(st, pos, normal) : 1.0f;
+    }
     const uint32_t seed0 =
-        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + time_ * 2671.918f);
     if (active) {
       RM_WS(ws_probes++);
       lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
@@ -960,6 +1000,7 @@ struct Tracer {
       if (t < tasks) {
         int probe, rank;
         divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
+        RM_CLK_T(ck_a0);
         const int owner = lds_map(rank);
         const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
         const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
@@ -977,8 +1018,10 @@ struct Tracer {
         float sd, scode;
         v3 nn;
         const v3 rpos = mads(n, d, opos);
-        scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false,
-                       ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2));
+        const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
+        RM_CLK_T(ck_a1);
+        RM_CLK_ADD(10, ck_a0, ck_a1);
+        scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
         lds_res(probe, owner) = sd;
       }
     }
@@ -1018,6 +1061,7 @@ struct Tracer {
       const int t = base + dl.my_slot;
       if (t < tasks) {
         int light, rank;
+        RM_CLK_T(ck_s0);
         divmod_small(t, dl.owners, light, rank);
         const int owner = lds_map(rank);
         const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
@@ -1030,6 +1074,8 @@ struct Tracer {
           const v3 ldir = normalize(dlv);
           const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
           Hit h{};
+          RM_CLK_T(ck_s1);
+          RM_CLK_ADD(11, ck_s0, ck_s1);
           march(mads(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
           lds_res(light, owner) = h.distance;
         }
@@ -1039,15 +1085,54 @@ struct Tracer {
     wave_sync();
   }
 
-  // lighting() with the rays of all hits of the wavefront traced together
-  RM_DEV v3 lighting_wave(bool active, const Sample& s, v3 raydir, v3 hitpos, const Material& m,
-                          v3 normal, v3 reflectCol) {
+  // the arithmetic of lighting() (renderer.cl:348-381) for a shading point whose rays have been
+  // traced: ao from occlusion_wave(), shadow march results of this lane in lds_res(i, lane)
+  RM_DEV v3 lighting_math(v3 raydir, v3 hitpos, const Material& m, v3 normal, v3 reflectCol, float ao, v3 jit) {
     const RmOpts& o = *sc.o;
+    const int lane = (int)(threadIdx.x & 63);
+    v3 diff = sky(normal) * ao;
+    v3 spec = reflectCol * ao;
+    v3 out = V(0.f, 0.f, 0.f);
+    const int nl = o.numLights;
+    for (int i = 0; i < nl; i++) {
+      const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
+      const float d2 = dot(dl, dl);
+      const float att = 1.0f / d2;
+      if (att > o.minLightAtt) {
+        const v3 ldir = normalize(dl);
+        const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
+        const float sh = rmd::step_cl(lmax, lds_res(i, lane));
+#ifdef RM_WORK_STATS
+        ws_pairs++;
+        if (rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f) {
+          ws_pairs_back++;
+          if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
+        }
+#endif
+        if (sh > 0.0f) {
+          const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
+          diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+          spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+        }
+      }
+      diff = diff * m.albedo;
+      out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
+    }
+    const float fl = (float)nl;
+    return V(out.x / fl, out.y / fl, out.z / fl);
+  }
+
+  // lighting() of one shading point per lane with the rays of all of the wavefront's points
+  // traced together.  The material comes in as its index and the reflected colour is either
+  // given (primary hit) or the sky seen along the mirror direction (bounce hits, renderer.cl:399):
+  // neither occupies registers while the rays are traced.
+  RM_DEV_LIGHT v3 lighting_wave(bool active, uint32_t lseed, v3 raydir, v3 hitpos, int objectID, v3 normal,
+                                bool mirror_sky, v3 reflectCol) {
     if (__ballot(active) == 0) return V(0.f, 0.f, 0.f);  // uniform
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_c0 = ws_now();
 #endif
-    const float ao = occlusion_wave(active, s, hitpos, normal);
+    const float ao = occlusion_wave(active, hitpos, normal);
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_c1 = ws_now();
     if (ws_c0 && ws_c1) ws_clk[2] += ws_c1 - ws_c0;
@@ -1055,7 +1140,7 @@ struct Tracer {
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
-      const float4 r = table(rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
+      const float4 r = table(lseed);
       jit = V(r.x, r.y, r.z);
     }
 #ifdef RM_PHASE_CLOCK
@@ -1068,37 +1153,9 @@ struct Tracer {
 #endif
     v3 res = V(0.f, 0.f, 0.f);
     if (active) {
-      v3 diff = sky(normal) * ao;
-      v3 spec = reflectCol * ao;
-      v3 out = V(0.f, 0.f, 0.f);
-      const int nl = o.numLights;
-      const int lane = (int)(threadIdx.x & 63);
-      for (int i = 0; i < nl; i++) {
-        const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
-        const float d2 = dot(dl, dl);
-        const float att = 1.0f / d2;
-        if (att > o.minLightAtt) {
-          const v3 ldir = normalize(dl);
-          const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
-          const float sh = rmd::step_cl(lmax, lds_res(i, lane));
-#ifdef RM_WORK_STATS
-          ws_pairs++;
-          if (rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f) {
-            ws_pairs_back++;
-            if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
-          }
-#endif
-          if (sh > 0.0f) {
-            const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-            diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
-            spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
-          }
-        }
-        diff = diff * m.albedo;
-        out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
-      }
-      const float fl = (float)nl;
-      res = V(out.x / fl, out.y / fl, out.z / fl);
+      const Material m = material(objectID);
+      if (mirror_sky) reflectCol = sky(reflect(raydir, normal));
+      res = lighting_math(raydir, hitpos, m, normal, reflectCol, ao, jit);
     }
     wave_sync();  // results consumed before the next shared phase posts
 #ifdef RM_PHASE_CLOCK
@@ -1108,35 +1165,56 @@ struct Tracer {
     return res;
   }
 
-  // sample_colour() with wave-uniform control flow around the shared phases.  A lane that is
-  // not `live` owns no sample in this turn (its pass lies beyond the frame's last): it traces
-  // nothing of its own but still deals with the other lanes' secondary rays.
-  RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
+  // shade() with wave-uniform control flow around the shared phases; every lane of the
+  // wavefront that has a pixel must call it (lanes without one have left the kernel),
+  // lds = kWaveLdsFloats floats.  A lane that is not `live` owns no sample in this turn (its
+  // pass lies beyond the frame's last): it traces nothing of its own but still deals with the
+  // other lanes' secondary rays.
+  //
+  // Register diet: the secondary-ray phases need ~35 registers of their own, so what a sample
+  // keeps across them decides how much of it is spilled to scratch (and scratch traffic competes
+  // with the table fetches for the caches).  Kept: the hits (position, normal, distance, material
+  // INDEX), the running reflection colour and two seeds.  Recomputed from the work-item id when
+  // next needed -- same operations, same bits: the sample's jitter vectors, eye position and
+  // camera ray (two table reads + ~120 instructions), materials (record loads), mirror-sky colours.
+  RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
+    lds_ = lds;
     const RmOpts& o = *sc.o;
     Hit h{};
+    v3 norm = V(0.f, 0.f, 0.f), dir = V(0.f, 0.f, 0.f);
+    uint32_t lseed;
+    bool hit, bounces;
+    {
+      RM_CLK_T(ck_c0);
+      const Sample s = sample_init(id);
+      const v3 rdir = camera_dir(s);
+      RM_CLK_T(ck_c1);
+      RM_CLK_ADD(12, ck_c0, ck_c1);
+      lseed = light_seed(s);
 #ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_p0 = ws_now();
+      const unsigned long long ws_p0 = ws_now();
 #endif
-    if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
+      if (live) march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
 #ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_p1 = ws_now();
-    if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
+      const unsigned long long ws_p1 = ws_now();
+      if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
 #endif
-    const bool hit = live && !(h.distance >= o.maxDist);
-    Material m{V(0.f, 0.f, 0.f), 0.f, 0.f};
-    v3 norm = V(0.f, 0.f, 0.f);
-    if (hit) {
-      m = material(h.objectID);
-      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
-      norm = mads(s.mcNormal, k, h.normal);
+      hit = live && !(h.distance >= o.maxDist);
+      float r0 = 0.0f;
+      if (hit) {
+        const Material m = material(h.objectID);
+        const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+        norm = mads(s.mcNormal, k, h.normal);  // renderer.cl:420
+        r0 = m.r0;
+      }
+      bounces = hit && r0 > 0.0f && o.reflectIter > 0;
+      dir = rdir;  // (the first bounce reflects the camera ray)
     }
-    const bool bounces = hit && m.r0 > 0.0f && o.reflectIter > 0;
     v3 refl = V(0.f, 0.f, 0.f);
     if (__ballot(bounces) != 0) {  // uniform
       Hit rh{};
       rh.pos = h.pos;
       rh.normal = norm;
-      v3 dir = rdir;
       bool alive = bounces;
       for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
         if (__ballot(alive) == 0) break;         // uniform
@@ -1156,34 +1234,59 @@ struct Tracer {
         if (ws_b0 && ws_b1) ws_clk[1] += ws_b1 - ws_b0;
 #endif
         const bool bhit = alive && rh.objectID >= 0;
-        Material bm{V(0.f, 0.f, 0.f), 0.f, 0.f};
-        v3 brefl = V(0.f, 0.f, 0.f);
-        if (bhit) {
-          bm = material(rh.objectID);
-          brefl = sky(reflect(dir, rh.normal));
-        }
-        const v3 lit = lighting_wave(bhit, s, dir, rh.pos, bm, rh.normal, brefl);
+        const v3 lit = lighting_wave(bhit, lseed, dir, rh.pos, rh.objectID, rh.normal, true, V(0.f, 0.f, 0.f));
         if (alive) {
           const v3 col = bhit ? lit : sky(dir);
-          refl = refl + atmosphere(s, from, dir, rh.distance, col);
+          refl = refl + atmosphere_seed(lseed, from, dir, rh.distance, col);
           if (rh.objectID < 0) alive = false;
           else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
         }
       }
     }
-    if (hit && !bounces) refl = sky(reflect(rdir, norm));
-    const v3 lit = lighting_wave(hit, s, rdir, h.pos, m, norm, refl);
-    const v3 col = hit ? lit : sky(rdir);
-    return atmosphere(s, ro, rdir, h.distance, col);
-  }
-
-  // shade() through the wave-shared path; every lane of the wavefront that has a pixel
-  // must call it (lanes without one have left the kernel), lds = kWaveLdsFloats floats
-  RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
-    lds_ = lds;
-    const Sample s = sample_init(id);
+    // the primary hit's rays; its arithmetic needs the camera ray again
+    if (__ballot(hit) == 0) {  // uniform: nothing to light in this wavefront
+      int id2 = id;
+      asm volatile("" : "+v"(id2));
+      const Sample s = sample_init(id2);
+      const v3 rdir = camera_dir(s);
+      return atmosphere_seed(lseed, s.eye, rdir, h.distance, sky(rdir)) * o.exposure;
+    }
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c0 = ws_now();
+#endif
+    const float ao = occlusion_wave(hit, h.pos, norm);
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c1 = ws_now();
+    if (ws_c0 && ws_c1) ws_clk[2] += ws_c1 - ws_c0;
+#endif
+    v3 jit = V(0.f, 0.f, 0.f);
+    if (hit) {
+      const float4 r = table(lseed);
+      jit = V(r.x, r.y, r.z);
+    }
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c2 = ws_now();
+#endif
+    shadows_wave(hit, h.pos, jit);
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c3 = ws_now();
+    if (ws_c2 && ws_c3) ws_clk[3] += ws_c3 - ws_c2;
+#endif
+    int id2 = id;
+    asm volatile("" : "+v"(id2));  // (a fresh evaluation, not values kept alive since the first one)
+    const Sample s = sample_init(id2);
     const v3 rdir = camera_dir(s);
-    return sample_colour_wave(s, s.eye, rdir, live) * sc.o->exposure;
+    v3 col = sky(rdir);
+    if (hit) {
+      if (!bounces) refl = sky(reflect(rdir, norm));
+      col = lighting_math(rdir, h.pos, material(h.objectID), norm, refl, ao, jit);
+    }
+    wave_sync();  // results consumed before the next shared phase posts
+#ifdef RM_PHASE_CLOCK
+    const unsigned long long ws_c4 = ws_now();
+    if (ws_c3 && ws_c4) ws_clk[4] += ws_c4 - ws_c3;
+#endif
+    return atmosphere_seed(lseed, s.eye, rdir, h.distance, col) * o.exposure;
   }
 
   // colour * exposure of work-item `id` (the value RenderImage blends in, renderer.cl:491)

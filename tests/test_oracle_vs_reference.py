@@ -79,3 +79,24 @@ def test_contraction_unstable_fraction_is_small(oracle_mod):
     rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-6)
     frac = float((rel.reshape(-1, 4)[:, :3].max(axis=1) > 1e-4).mean())
     assert frac < 0.05
+
+
+def test_libm_backed_reference_build_meets_the_metric(oracle_mod):
+    """The oracle's exp / exp2 / pow are deterministic stand-ins (oracle/cl_scalar.h).  A build of
+    the reference kernel that takes them from the host libm instead -- what a CPU OpenCL runtime
+    would most likely do -- agrees with the oracle on BASELINE.json's metric (1e-4 relative) for
+    every pixel, and bit for bit on almost all (tools/pin_report.py: profiles/r02_pin_report.txt)."""
+    if not oracle_mod.have_ref("libm"):
+        pytest.skip("libm build missing")
+    for name in ("c1_orange", "metal_3spp", "blobs_metal"):
+        sc = scenes.build(name)
+        n = sc["n"]
+        a = np.zeros(4 * n, np.float32)
+        b = np.zeros(4 * n, np.float32)
+        for i in range(sc["iter"]):
+            o = sc["opts"][i * 544:(i + 1) * 544]
+            oracle_mod.ref_render_image(sc["vox"], sc["mc"][i].copy(), o, a)
+            oracle_mod.ref_render_image(sc["vox"], sc["mc"][i].copy(), o, b, fma="libm")
+        rel = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+        assert rel.max() <= 1e-4, (name, float(rel.max()))
+        assert (a.view(np.uint32) == b.view(np.uint32)).mean() > 0.99
