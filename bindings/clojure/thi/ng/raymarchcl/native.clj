@@ -1,40 +1,147 @@
-;; native.clj -- what a maintainer of thi-ng/raymarchcl adds to run the render
-;; path on libraymarch_hip.so instead of OpenCL.  UNVERIFIED HERE (no JVM in the
-;; build image).  It keeps the signatures of the reference's host functions
-;; (core.clj): `init-renderer` still returns a state map, `execute` still
-;; returns the IntBuffer of packed ARGB pixels that test-render copies into a
-;; BufferedImage (core.clj:171-179).  structgen's `sg/encode` keeps producing
-;; the 544-byte TRenderOpts records (core.clj:99-106) -- the native library
-;; consumes exactly that layout.
+;; native.clj -- the reference's host entry points on libraymarch_hip.so instead of OpenCL.
+;;
+;; What a maintainer of thi-ng/raymarchcl adds next to src/thi/ng/raymarchcl/core.clj.  The
+;; parameter layer is REUSED from core.clj (render-options, compute-eyepos and the struct
+;; registry it fills from renderer.cl's typedef, core.clj:24-74,150-152); what thi.ng.simplecl
+;; did -- context, buffers, the compiled pipeline of core.clj:76-148 -- becomes calls of
+;; thi.ng.raymarchcl.Native (bindings/java/.../Native.java over bindings/jni/raymarch_jni.c).
+;; init-renderer, make-render-option-buffer, update-render-option-buffer, test-render and
+;; test-anim keep the reference's names and parameter lists (core.clj:99-213).
+;;
+;; UNVERIFIED HERE: the build image has no JVM.  tests/test_jni_shim.py checks statically that
+;; the parameter lists match the reference's and that only declared natives are called; the JNI
+;; shim itself is compiled and run from C on the GPU.
 (ns thi.ng.raymarchcl.native
-  (:import [java.nio ByteBuffer ByteOrder]))
+  (:require
+   [thi.ng.raymarchcl.core :as core]
+   [thi.ng.raymarchcl.generators :as gen]
+   [thi.ng.raymarchcl.io :as vio]
+   [thi.ng.structgen.core :as sg]
+   [thi.ng.math.core :as m]
+   [piksel.core :as pix])
+  (:import
+   [java.nio ByteBuffer ByteOrder FloatBuffer IntBuffer]
+   [thi.ng.raymarchcl Native]))
 
-(gen-class
- :name thi.ng.raymarchcl.Native
- :methods [^:static [create [int] long]
-           ^:static [destroy [long] void]
-           ^:static [setVolume [long java.nio.ByteBuffer int int int] int]
-           ^:static [renderImage [long java.nio.ByteBuffer java.nio.ByteBuffer java.nio.ByteBuffer int] int]
-           ^:static [tonemapImage [long java.nio.ByteBuffer java.nio.ByteBuffer java.nio.ByteBuffer int] int]
-           ^:static [renderFrame [long java.nio.ByteBuffer java.nio.ByteBuffer int int
-                                  java.nio.ByteBuffer java.nio.ByteBuffer] int]])
-;; (in practice: a 10-line Java class with `static native` methods and
-;;  System.loadLibrary("raymarch_jni"); gen-class cannot declare natives)
+(def ^:const record-bytes 544)          ; sizeof(TRenderOpts), renderer.cl:35-78
+(def ^:const table-floats (* 0x4000 4)) ; one scatter table, generators.clj:8-16
 
-(defn direct [n] (.order (ByteBuffer/allocateDirect n) (ByteOrder/nativeOrder)))
+;; unchanged host functions of the reference
+(def render-options core/render-options)   ; [{:keys [width height vres t iter eyepos mat fov dof targetpos gamma groundY voxelSize] :as opts}]
+(def compute-eyepos core/compute-eyepos)   ; [theta dist y]
+
+(defn direct
+  "n bytes of direct memory in native byte order (what JOCL's buffers are in the reference)."
+  ^ByteBuffer [n]
+  (.order (ByteBuffer/allocateDirect n) (ByteOrder/nativeOrder)))
+
+(defn- fill-records!
+  "Encodes one TRenderOpts per pass into `buf`, pass i at time i*dt."
+  [^ByteBuffer buf opts dt]
+  (let [layout (sg/lookup :TRenderOpts)
+        passes (quot (.capacity buf) record-bytes)]
+    (.clear buf)
+    (dotimes [i passes]
+      (.put buf ^ByteBuffer (.rewind ^ByteBuffer (sg/encode layout (render-options (assoc opts :t (* i dt)))))))
+    (.rewind buf)
+    buf))
+
+(defn make-render-option-buffer
+  "As core.clj:99-106 (pass i at t = 0.333 i), but ONE direct buffer of n records back to back
+  -- the library's opts_array -- instead of n OpenCL buffers."
+  [n opts]
+  (fill-records! (direct (* n record-bytes)) opts 0.333))
+
+(defn update-render-option-buffer
+  "As core.clj:108-117: re-encodes in place; note the reference's other time step, 0.3333."
+  [buffers opts]
+  (fill-records! buffers opts 0.3333))
+
+(defn- scatter-tables
+  ^ByteBuffer [passes]
+  (let [buf (direct (* passes table-floats 4))
+        fb  (.asFloatBuffer buf)]
+    (dotimes [_ passes]
+      (.put ^FloatBuffer fb (float-array (gen/generate-scatter-offsets 0x4000))))
+    buf))
+
+(defn- as-direct
+  ^ByteBuffer [^ByteBuffer b]
+  (if (.isDirect b)
+    b
+    (doto (direct (.remaining b)) (.put (.duplicate b)) (.rewind))))
+
+(defn- open-device
+  "One GPU, or -- with :devices n in the renderer args -- the first n GPUs of the node sharing
+  every frame (image tiles; tile accumulators gathered on GPU 0 inside the library)."
+  [n]
+  (if (> n 1)
+    (let [ids (direct (* 4 n))]
+      (dotimes [i n] (.putInt ids (* 4 i) i))
+      (Native/createMulti ids n))
+    (Native/create 0)))
 
 (defn init-renderer
-  "As core/init-renderer (core.clj:119-148), minus the OpenCL state."
-  [{:keys [width height iter opts-bytes mc-floats voxels vres]}]
-  (let [h (thi.ng.raymarchcl.Native/create 0)]
-    (thi.ng.raymarchcl.Native/setVolume h voxels (vres 0) (vres 1) (vres 2))
-    {:handle h :num (* width height) :iter iter
-     :opts opts-bytes   ; iter x 544 B, from (sg/encode t-opts (render-options ...))
-     :mc mc-floats      ; iter x 0x4000 x 4 floats, from gen/generate-scatter-offsets
-     :q-buf (direct (* 4 width height))}))
+  [{:keys [width height vres iter vname] :as args}]
+  (let [[rx ry rz] (if (number? vres) [vres vres vres] vres)
+        handle     (open-device (get args :devices 1))
+        pixels     (* width height)]
+    (Native/setVolume handle (as-direct (vio/load-volume (or vname "gyroid-sliced-512-s0.01.vox"))) rx ry rz)
+    {:handle       handle
+     :num          pixels
+     :iter         iter
+     :opts-buffers (make-render-option-buffer iter args)
+     :mc-buffers   (scatter-tables iter)
+     :q-buf        (direct (* 4 pixels))}))
 
-(defn execute
-  "As (ops/execute-pipeline (:pipeline state) ...) (core.clj:171): returns the ARGB IntBuffer."
-  [{:keys [handle num iter opts mc q-buf]}]
-  (thi.ng.raymarchcl.Native/renderFrame handle opts mc iter num nil q-buf)
-  (.asIntBuffer q-buf))
+(defn execute-pipeline
+  "The reference's (ops/execute-pipeline (:pipeline state) ...), core.clj:76-97 + :171, as one
+  native call: zeroed accumulator, `iter` RenderImage passes in order, TonemapImage with the
+  first record; returns the packed ARGB pixels."
+  ^IntBuffer [{:keys [handle opts-buffers mc-buffers iter num q-buf]}]
+  (Native/renderFrame handle opts-buffers mc-buffers iter num nil q-buf)
+  (.asIntBuffer ^ByteBuffer (.rewind ^ByteBuffer q-buf)))
+
+(defn release [state] (Native/destroy (:handle state)))
+
+(defn- save-frame!
+  [^IntBuffer argb img path]
+  (let [dst (pix/get-pixels img)]
+    (.get argb dst)
+    (pix/set-pixels img dst)
+    (pix/save-png img path)))
+
+(defn test-render
+  [& {:keys [width height iter vres mat vname out-path theta dist]
+      :or {width 640 height 360 iter 1 vres 256 mat :metal out-path "foo.png"
+           theta 135 dist 2.25}
+      :as opts}]
+  (let [camera {:eyepos (compute-eyepos theta dist 0.35) :targetpos [0 -0.4 0]}
+        state  (init-renderer (merge {:width width :height height :vres vres :iter iter :mat mat :vname vname}
+                                     camera opts))]
+    (try
+      (save-frame! (time (execute-pipeline state)) (pix/make-image width height) out-path)
+      (finally (release state)))))
+
+(def ^:private orbit
+  "The camera path of the reference's animation (core.clj:192-198): 35 frames around the volume."
+  {:frames 35 :theta [0 350] :radius [2.25 2.25] :eye-y [0.44 0.45] :target-y [-0.15 -0.15] :fov [115 115]})
+
+(defn- orbit-args
+  [frame]
+  (let [t  (m/map-interval frame 0 (:frames orbit) 0.0 1.0)
+        at (fn [k] (let [[a b] (orbit k)] (m/map-interval t 0 1 a b)))]
+    {:fov (at :fov) :targetpos [0 (at :target-y) 0] :eyepos (compute-eyepos (at :theta) (at :radius) (at :eye-y))}))
+
+(defn test-anim
+  [width height iter res mat & vname]
+  (let [args  {:width width :height height :vres [res res res] :iter iter :mat mat :vname (first vname)}
+        img   (pix/make-image width height)
+        state (init-renderer args)]
+    (try
+      (time
+       (doseq [frame (range (:frames orbit))]
+         (prn "rendering frame #" frame)
+         (update-render-option-buffer (:opts-buffers state) (merge args (orbit-args frame)))
+         (save-frame! (time (execute-pipeline state)) img (format "export/frame-%04d.png" frame))))
+      (finally (release state)))))

@@ -2,22 +2,26 @@
  * raymarch_jni.c -- thin JNI shim over the C ABI of libraymarch_hip.so
  * (include/raymarch_hip.h) for the reference's Clojure host.
  *
- * UNVERIFIED IN THIS REPOSITORY'S BUILD IMAGE: the image has no JDK (no jni.h,
- * no javac, no lein), so this file is compiled and exercised nowhere here; it
- * is the binding a maintainer adds on a machine with a JDK:
+ * The build image has no JDK (no jni.h, no javac, no lein).  What IS checked here:
+ * tests/test_jni_shim.py compiles this file against bindings/jni/test/jni.h -- a hand-written
+ * declaration guard holding the handful of JNI declarations the shim uses -- and drives every
+ * Java_* entry point from a C harness through a stand-in JNIEnv function table
+ * (bindings/jni/test/harness.c), on the GPU, comparing with direct C-ABI calls.  On a machine
+ * with a JDK a maintainer builds it against the real header:
  *
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux \
  *       -I../../include raymarch_jni.c -L../../raymarchcl_amd -lraymarch_hip \
  *       -o libraymarch_jni.so
  *
- * Java/Clojure side: class thi.ng.raymarchcl.Native with the static native
- * methods below (see bindings/clojure/thi/ng/raymarchcl/native.clj).  All
- * buffers are DIRECT java.nio buffers, exactly what thi.ng.simplecl hands to
- * JOCL in the reference (core.clj:137-145, io.clj:29-33).  A non-zero return
- * code of the C ABI becomes a RuntimeException carrying rm_last_error().
+ * Java side: class thi.ng.raymarchcl.Native (bindings/java/thi/ng/raymarchcl/Native.java) with
+ * the static native methods below; Clojure side: bindings/clojure/thi/ng/raymarchcl/native.clj.
+ * All buffers are DIRECT java.nio buffers, exactly what thi.ng.simplecl hands to JOCL in the
+ * reference (core.clj:137-145, io.clj:29-33).  A non-zero return code of the C ABI becomes a
+ * RuntimeException carrying rm_last_error().
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stddef.h>
 
 #include "raymarch_hip.h"
 
@@ -28,42 +32,108 @@ static jint check(JNIEnv* env, int rc) {
   }
   return rc;
 }
-static void* addr(JNIEnv* env, jobject buf) { return buf ? (*env)->GetDirectBufferAddress(env, buf) : NULL; }
+/* a direct buffer that must hold at least `bytes`; throws and returns NULL otherwise */
+static void* addr_of(JNIEnv* env, jobject buf, jlong bytes, const char* what) {
+  if (!buf) return NULL;
+  void* p = (*env)->GetDirectBufferAddress(env, buf);
+  const jlong cap = (*env)->GetDirectBufferCapacity(env, buf);
+  if (!p || cap < bytes) {
+    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (ex) (*env)->ThrowNew(env, ex, what);
+    return NULL;
+  }
+  return p;
+}
+#define CTX(h) ((rm_ctx*)(intptr_t)(h))
 
-/* init-renderer's cl/init-state (core.clj:121-128) */
+/* init-renderer's cl/select-platform .. cl/init-state (core.clj:121-128) */
 JNIEXPORT jlong JNICALL Java_thi_ng_raymarchcl_Native_create(JNIEnv* env, jclass c, jint device) {
   rm_ctx* ctx = NULL;
+  (void)c;
   check(env, rm_create(device, &ctx));
   return (jlong)(intptr_t)ctx;
 }
+/* the same over the first `nDevices` GPUs of the node: frames are tiled over them */
+JNIEXPORT jlong JNICALL Java_thi_ng_raymarchcl_Native_createMulti(JNIEnv* env, jclass c, jobject deviceIds,
+                                                                  jint nDevices) {
+  rm_ctx* ctx = NULL;
+  (void)c;
+  const int* ids = (const int*)addr_of(env, deviceIds, (jlong)nDevices * 4, "deviceIds: direct IntBuffer too small");
+  if (!ids) return 0;
+  check(env, rm_create_multi(ids, nDevices, &ctx));
+  return (jlong)(intptr_t)ctx;
+}
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_deviceCount(JNIEnv* env, jclass c) {
+  (void)env; (void)c;
+  return rm_device_count();
+}
 JNIEXPORT void JNICALL Java_thi_ng_raymarchcl_Native_destroy(JNIEnv* env, jclass c, jlong h) {
-  rm_destroy((rm_ctx*)(intptr_t)h);
+  (void)env; (void)c;
+  rm_destroy(CTX(h));
 }
 /* v-buf of vio/load-volume (io.clj:19-33) */
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_setVolume(JNIEnv* env, jclass c, jlong h,
                                                               jobject vox, jint rx, jint ry, jint rz) {
-  return check(env, rm_set_volume((rm_ctx*)(intptr_t)h, (const uint8_t*)addr(env, vox), rx, ry, rz));
+  (void)c;
+  const uint8_t* p = (const uint8_t*)addr_of(env, vox, (jlong)rx * ry * rz, "voxels: direct ByteBuffer too small");
+  if (!p) return RM_EINVAL;
+  return check(env, rm_set_volume(CTX(h), p, rx, ry, rz));
+}
+/* gen/make-gyroid-volume (generators.clj:27-42) on the device; voxelsOut may be null */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_makeGyroidVolume(JNIEnv* env, jclass c, jlong h, jint rx,
+                                                                     jint ry, jint rz, jobject voxelsOut) {
+  (void)c;
+  uint8_t* p = (uint8_t*)addr_of(env, voxelsOut, (jlong)rx * ry * rz, "voxelsOut: direct ByteBuffer too small");
+  if (voxelsOut && !p) return RM_EINVAL;
+  return check(env, rm_make_gyroid_volume(CTX(h), rx, ry, rz, p));
 }
 /* one RenderImage step of the pipeline (core.clj:84-89) */
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_renderImage(JNIEnv* env, jclass c, jlong h,
                                                                 jobject mc, jobject opts, jobject pixels,
                                                                 jint n) {
-  return check(env, rm_render_image((rm_ctx*)(intptr_t)h, (const float*)addr(env, mc), addr(env, opts),
-                                    (float*)addr(env, pixels), n));
+  (void)c;
+  const float* pm = (const float*)addr_of(env, mc, (jlong)RM_TABLE_FLOATS * 4, "mc: needs 0x4000 float4");
+  const void* po = addr_of(env, opts, RM_OPTS_BYTES, "opts: needs 544 bytes");
+  float* pp = (float*)addr_of(env, pixels, (jlong)n * 16, "pixels: needs n float4");
+  if (!pm || !po || !pp) return RM_EINVAL;
+  return check(env, rm_render_image(CTX(h), pm, po, pp, n));
 }
 /* the TonemapImage step (core.clj:91-97) */
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_tonemapImage(JNIEnv* env, jclass c, jlong h,
                                                                  jobject pixels, jobject opts,
                                                                  jobject argb, jint n) {
-  return check(env, rm_tonemap_image((rm_ctx*)(intptr_t)h, (const float*)addr(env, pixels),
-                                     addr(env, opts), (uint32_t*)addr(env, argb), n));
+  (void)c;
+  const float* pp = (const float*)addr_of(env, pixels, (jlong)n * 16, "pixels: needs n float4");
+  const void* po = addr_of(env, opts, RM_OPTS_BYTES, "opts: needs 544 bytes");
+  uint32_t* pa = (uint32_t*)addr_of(env, argb, (jlong)n * 4, "argb: needs n ints");
+  if (!pp || !po || !pa) return RM_EINVAL;
+  return check(env, rm_tonemap_image(CTX(h), pp, po, pa, n));
 }
-/* ops/execute-pipeline of make-pipeline (core.clj:76-97, 171) */
+/* ops/execute-pipeline of make-pipeline (core.clj:76-97, 171); pixelsOut / argbOut may be null */
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_renderFrame(JNIEnv* env, jclass c, jlong h,
                                                                 jobject optsArray, jobject mcArray,
                                                                 jint iter, jint n, jobject pixelsOut,
                                                                 jobject argbOut) {
-  return check(env, rm_render_frame((rm_ctx*)(intptr_t)h, addr(env, optsArray),
-                                    (const float*)addr(env, mcArray), iter, n,
-                                    (float*)addr(env, pixelsOut), (uint32_t*)addr(env, argbOut)));
+  (void)c;
+  const void* po = addr_of(env, optsArray, (jlong)iter * RM_OPTS_BYTES, "optsArray: needs iter x 544 bytes");
+  const float* pm = (const float*)addr_of(env, mcArray, (jlong)iter * RM_TABLE_FLOATS * 4, "mcArray: needs iter tables");
+  float* pp = (float*)addr_of(env, pixelsOut, (jlong)n * 16, "pixelsOut: needs n float4");
+  uint32_t* pa = (uint32_t*)addr_of(env, argbOut, (jlong)n * 4, "argbOut: needs n ints");
+  if (!po || !pm || (pixelsOut && !pp) || (argbOut && !pa)) return RM_EINVAL;
+  return check(env, rm_render_frame(CTX(h), po, pm, iter, n, pp, pa));
+}
+/* device time of the render kernel(s) of the last frame, in milliseconds (< 0: none yet) */
+JNIEXPORT jfloat JNICALL Java_thi_ng_raymarchcl_Native_lastFrameMillis(JNIEnv* env, jclass c, jlong h) {
+  float ms = -1.0f;
+  (void)env; (void)c;
+  if (rm_last_frame_timing(CTX(h), &ms, NULL) != RM_OK) return -1.0f;
+  return ms;
+}
+/* gen/generate-scatter-offsets (generators.clj:8-16) with a seed; out: 0x4000 float4 */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_makeScatterTable(JNIEnv* env, jclass c, jlong seed,
+                                                                     jobject out) {
+  (void)c;
+  float* p = (float*)addr_of(env, out, (jlong)RM_TABLE_FLOATS * 4, "out: needs 0x4000 float4");
+  if (!p) return RM_EINVAL;
+  return check(env, rm_make_scatter_table((uint64_t)seed, p));
 }

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   unsigned long long ws_acc[64];
   for (int k = 0; k < 64; k++) ws_acc[k] = 0ull;
 #endif
-  for (int c0 = 0; c0 < (MULTI ? a.passes : 1); c0 += pp) {
+  for (int c0 = 0; MULTI ? c0 < a.passes : c0 == 0; c0 += MULTI ? pp : 1) {
     const int pass = c0 + pl;
 #ifdef RM_AB_NOLIVE
     const bool live = true;  // (A/B only: valid when passes is a multiple of pp)

@@ -192,13 +192,6 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 // 11.10 / 11.16 ms with the first / second / both: register pressure); with the shared
 // phases 8.87 ms without, 8.78 / 8.89 / 8.73 ms.  Switchable for re-measuring
 // (tools/ab_build.py).
-// A/B: lighting_wave() out of line (one copy, a call boundary as the spill point) -- measured
-// equal to inlining on the 5.3 ms build
-#ifdef RM_NOINLINE_LIGHT
-#define RM_DEV_LIGHT __device__ __attribute__((noinline))
-#else
-#define RM_DEV_LIGHT RM_DEV
-#endif
 #ifndef RM_FASTDIV
 #define RM_FASTDIV 1      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
 #endif
@@ -742,30 +735,23 @@ struct Tracer {
 
   struct Sample { v3 eye; v3 mcNormal; float px, py; float time; };
 
-  // jittered light position: renderer.cl:263-269.  The table index depends on the sample only
-  // (one jitter for all lights and all shading points of a sample): light_seed().
-  RM_DEV static uint32_t light_seed(const Sample& s) {
-    return rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
-  }
-  RM_DEV v3 light_at_seed(uint32_t seed, int i) {
+  // jittered light position: renderer.cl:263-269
+  RM_DEV v3 light_at(const Sample& s, int i) {
     const RmOpts& o = *sc.o;
+    const uint32_t seed = rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
     const float4 r = table(seed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
-  RM_DEV v3 light_at(const Sample& s, int i) { return light_at_seed(light_seed(s), i); }
   RM_DEV v3 reflect(v3 v, v3 n) { return reflect_of(v, n); }
   // fog + flares: renderer.cl:275-290
   RM_DEV v3 atmosphere(const Sample& s, v3 ro, v3 rdir, float dist, v3 col) {
-    return atmosphere_seed(light_seed(s), ro, rdir, dist, col);
-  }
-  RM_DEV v3 atmosphere_seed(uint32_t lseed, v3 ro, v3 rdir, float dist, v3 col) {
     const RmOpts& o = *sc.o;
     const float fa = 1.0f - rmd::exp_det(dist * dist * -o.fogPow);
     const v3 sk = sky(rdir);
     col = V((sk.x - col.x) * fa + col.x, (sk.y - col.y) * fa + col.y, (sk.z - col.z) * fa + col.z);
     const int nl = o.numLights;
     for (int i = 0; i < nl; i++) {
-      v3 lp = light_at_seed(lseed, i);
+      v3 lp = light_at(s, i);
       const float d = rmd::clamp_cl(dot(lp - ro, rdir), 0.0f, dist);
       lp = mads(rdir, d, ro - lp);
       const float k = o.flareAmp / dot(lp, lp);
@@ -966,19 +952,14 @@ struct Tracer {
   }
 
   // occlusion() for all lanes of the wavefront at once; `active` lanes own a hit
-  // (s.time of the reference's seed is this lane's pass time: time_)
-  RM_DEV float occlusion_wave(bool active, v3 pos, v3 normal) {
+  RM_DEV float occlusion_wave(bool active, const Sample& s, v3 pos, v3 normal) {
     const RmOpts& o = *sc.o;
     const int np = o.aoIter + 1;
     const Deal dl = deal(active);
     if (dl.owners == 0) return 1.0f;
-    if (np > kWaveLdsRes) {  // (uniform) too many probes to post: every owner traces its own
-      Sample st{};
-      st.time = time_;
-      return active ? occlusion(st, pos, normal) : 1.0f;
-    }
+    if (np > kWaveLdsRes) return active ? occlusion(s, pos, normal) : 1.0f;  // (uniform) too many probes to post
     const uint32_t seed0 =
-        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + time_ * 2671.918f);
+        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
     if (active) {
       RM_WS(ws_probes++);
       lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
@@ -1085,54 +1066,15 @@ struct Tracer {
     wave_sync();
   }
 
-  // the arithmetic of lighting() (renderer.cl:348-381) for a shading point whose rays have been
-  // traced: ao from occlusion_wave(), shadow march results of this lane in lds_res(i, lane)
-  RM_DEV v3 lighting_math(v3 raydir, v3 hitpos, const Material& m, v3 normal, v3 reflectCol, float ao, v3 jit) {
+  // lighting() with the rays of all hits of the wavefront traced together
+  RM_DEV v3 lighting_wave(bool active, const Sample& s, v3 raydir, v3 hitpos, int objectID,
+                          v3 normal, bool mirror_sky, v3 reflectCol) {
     const RmOpts& o = *sc.o;
-    const int lane = (int)(threadIdx.x & 63);
-    v3 diff = sky(normal) * ao;
-    v3 spec = reflectCol * ao;
-    v3 out = V(0.f, 0.f, 0.f);
-    const int nl = o.numLights;
-    for (int i = 0; i < nl; i++) {
-      const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
-      const float d2 = dot(dl, dl);
-      const float att = 1.0f / d2;
-      if (att > o.minLightAtt) {
-        const v3 ldir = normalize(dl);
-        const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
-        const float sh = rmd::step_cl(lmax, lds_res(i, lane));
-#ifdef RM_WORK_STATS
-        ws_pairs++;
-        if (rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f) {
-          ws_pairs_back++;
-          if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
-        }
-#endif
-        if (sh > 0.0f) {
-          const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-          diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
-          spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
-        }
-      }
-      diff = diff * m.albedo;
-      out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
-    }
-    const float fl = (float)nl;
-    return V(out.x / fl, out.y / fl, out.z / fl);
-  }
-
-  // lighting() of one shading point per lane with the rays of all of the wavefront's points
-  // traced together.  The material comes in as its index and the reflected colour is either
-  // given (primary hit) or the sky seen along the mirror direction (bounce hits, renderer.cl:399):
-  // neither occupies registers while the rays are traced.
-  RM_DEV_LIGHT v3 lighting_wave(bool active, uint32_t lseed, v3 raydir, v3 hitpos, int objectID, v3 normal,
-                                bool mirror_sky, v3 reflectCol) {
     if (__ballot(active) == 0) return V(0.f, 0.f, 0.f);  // uniform
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_c0 = ws_now();
 #endif
-    const float ao = occlusion_wave(active, hitpos, normal);
+    const float ao = occlusion_wave(active, s, hitpos, normal);
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_c1 = ws_now();
     if (ws_c0 && ws_c1) ws_clk[2] += ws_c1 - ws_c0;
@@ -1140,7 +1082,7 @@ struct Tracer {
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
-      const float4 r = table(lseed);
+      const float4 r = table(rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
       jit = V(r.x, r.y, r.z);
     }
 #ifdef RM_PHASE_CLOCK
@@ -1155,7 +1097,37 @@ struct Tracer {
     if (active) {
       const Material m = material(objectID);
       if (mirror_sky) reflectCol = sky(reflect(raydir, normal));
-      res = lighting_math(raydir, hitpos, m, normal, reflectCol, ao, jit);
+      v3 diff = sky(normal) * ao;
+      v3 spec = reflectCol * ao;
+      v3 out = V(0.f, 0.f, 0.f);
+      const int nl = o.numLights;
+      const int lane = (int)(threadIdx.x & 63);
+      for (int i = 0; i < nl; i++) {
+        const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
+        const float d2 = dot(dl, dl);
+        const float att = 1.0f / d2;
+        if (att > o.minLightAtt) {
+          const v3 ldir = normalize(dl);
+          const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
+          const float sh = rmd::step_cl(lmax, lds_res(i, lane));
+#ifdef RM_WORK_STATS
+          ws_pairs++;
+          if (rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f) {
+            ws_pairs_back++;
+            if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
+          }
+#endif
+          if (sh > 0.0f) {
+            const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
+            diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+            spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+          }
+        }
+        diff = diff * m.albedo;
+        out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
+      }
+      const float fl = (float)nl;
+      res = V(out.x / fl, out.y / fl, out.z / fl);
     }
     wave_sync();  // results consumed before the next shared phase posts
 #ifdef RM_PHASE_CLOCK
@@ -1165,56 +1137,36 @@ struct Tracer {
     return res;
   }
 
-  // shade() with wave-uniform control flow around the shared phases; every lane of the
-  // wavefront that has a pixel must call it (lanes without one have left the kernel),
-  // lds = kWaveLdsFloats floats.  A lane that is not `live` owns no sample in this turn (its
-  // pass lies beyond the frame's last): it traces nothing of its own but still deals with the
-  // other lanes' secondary rays.
-  //
-  // Register diet: the secondary-ray phases need ~35 registers of their own, so what a sample
-  // keeps across them decides how much of it is spilled to scratch (and scratch traffic competes
-  // with the table fetches for the caches).  Kept: the hits (position, normal, distance, material
-  // INDEX), the running reflection colour and two seeds.  Recomputed from the work-item id when
-  // next needed -- same operations, same bits: the sample's jitter vectors, eye position and
-  // camera ray (two table reads + ~120 instructions), materials (record loads), mirror-sky colours.
-  RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
-    lds_ = lds;
+  // sample_colour() with wave-uniform control flow around the shared phases.  A lane that is
+  // not `live` owns no sample in this turn (its pass lies beyond the frame's last): it traces
+  // nothing of its own but still deals with the other lanes' secondary rays.
+  RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
     const RmOpts& o = *sc.o;
     Hit h{};
-    v3 norm = V(0.f, 0.f, 0.f), dir = V(0.f, 0.f, 0.f);
-    uint32_t lseed;
-    bool hit, bounces;
-    {
-      RM_CLK_T(ck_c0);
-      const Sample s = sample_init(id);
-      const v3 rdir = camera_dir(s);
-      RM_CLK_T(ck_c1);
-      RM_CLK_ADD(12, ck_c0, ck_c1);
-      lseed = light_seed(s);
 #ifdef RM_PHASE_CLOCK
-      const unsigned long long ws_p0 = ws_now();
+    const unsigned long long ws_p0 = ws_now();
 #endif
-      if (live) march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
+    if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
 #ifdef RM_PHASE_CLOCK
-      const unsigned long long ws_p1 = ws_now();
-      if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
+    const unsigned long long ws_p1 = ws_now();
+    if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
 #endif
-      hit = live && !(h.distance >= o.maxDist);
-      float r0 = 0.0f;
-      if (hit) {
-        const Material m = material(h.objectID);
-        const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
-        norm = mads(s.mcNormal, k, h.normal);  // renderer.cl:420
-        r0 = m.r0;
-      }
-      bounces = hit && r0 > 0.0f && o.reflectIter > 0;
-      dir = rdir;  // (the first bounce reflects the camera ray)
+    const bool hit = live && !(h.distance >= o.maxDist);
+    v3 norm = V(0.f, 0.f, 0.f);
+    float r0 = 0.0f;
+    if (hit) {
+      const Material m = material(h.objectID);
+      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      norm = mads(s.mcNormal, k, h.normal);
+      r0 = m.r0;
     }
+    const bool bounces = hit && r0 > 0.0f && o.reflectIter > 0;
     v3 refl = V(0.f, 0.f, 0.f);
     if (__ballot(bounces) != 0) {  // uniform
       Hit rh{};
       rh.pos = h.pos;
       rh.normal = norm;
+      v3 dir = rdir;
       bool alive = bounces;
       for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
         if (__ballot(alive) == 0) break;         // uniform
@@ -1234,59 +1186,31 @@ struct Tracer {
         if (ws_b0 && ws_b1) ws_clk[1] += ws_b1 - ws_b0;
 #endif
         const bool bhit = alive && rh.objectID >= 0;
-        const v3 lit = lighting_wave(bhit, lseed, dir, rh.pos, rh.objectID, rh.normal, true, V(0.f, 0.f, 0.f));
+        const v3 lit = lighting_wave(bhit, s, dir, rh.pos, rh.objectID, rh.normal, true, V(0.f, 0.f, 0.f));
         if (alive) {
           const v3 col = bhit ? lit : sky(dir);
-          refl = refl + atmosphere_seed(lseed, from, dir, rh.distance, col);
+          refl = refl + atmosphere(s, from, dir, rh.distance, col);
           if (rh.objectID < 0) alive = false;
           else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
         }
       }
     }
-    // the primary hit's rays; its arithmetic needs the camera ray again
-    if (__ballot(hit) == 0) {  // uniform: nothing to light in this wavefront
-      int id2 = id;
-      asm volatile("" : "+v"(id2));
-      const Sample s = sample_init(id2);
-      const v3 rdir = camera_dir(s);
-      return atmosphere_seed(lseed, s.eye, rdir, h.distance, sky(rdir)) * o.exposure;
-    }
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c0 = ws_now();
-#endif
-    const float ao = occlusion_wave(hit, h.pos, norm);
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c1 = ws_now();
-    if (ws_c0 && ws_c1) ws_clk[2] += ws_c1 - ws_c0;
-#endif
-    v3 jit = V(0.f, 0.f, 0.f);
-    if (hit) {
-      const float4 r = table(lseed);
-      jit = V(r.x, r.y, r.z);
-    }
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c2 = ws_now();
-#endif
-    shadows_wave(hit, h.pos, jit);
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c3 = ws_now();
-    if (ws_c2 && ws_c3) ws_clk[3] += ws_c3 - ws_c2;
-#endif
-    int id2 = id;
-    asm volatile("" : "+v"(id2));  // (a fresh evaluation, not values kept alive since the first one)
-    const Sample s = sample_init(id2);
+    if (hit && !bounces) refl = sky(reflect(rdir, norm));
+    const v3 lit = lighting_wave(hit, s, rdir, h.pos, h.objectID, norm, false, refl);
+    const v3 col = hit ? lit : sky(rdir);
+    return atmosphere(s, ro, rdir, h.distance, col);
+  }
+
+  // shade() through the wave-shared path; every lane of the wavefront that has a pixel
+  // must call it (lanes without one have left the kernel), lds = kWaveLdsFloats floats
+  RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
+    lds_ = lds;
+    RM_CLK_T(ck_c0);
+    const Sample s = sample_init(id);
     const v3 rdir = camera_dir(s);
-    v3 col = sky(rdir);
-    if (hit) {
-      if (!bounces) refl = sky(reflect(rdir, norm));
-      col = lighting_math(rdir, h.pos, material(h.objectID), norm, refl, ao, jit);
-    }
-    wave_sync();  // results consumed before the next shared phase posts
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c4 = ws_now();
-    if (ws_c3 && ws_c4) ws_clk[4] += ws_c4 - ws_c3;
-#endif
-    return atmosphere_seed(lseed, s.eye, rdir, h.distance, col) * o.exposure;
+    RM_CLK_T(ck_c1);
+    RM_CLK_ADD(12, ck_c0, ck_c1);
+    return sample_colour_wave(s, s.eye, rdir, live) * sc.o->exposure;
   }
 
   // colour * exposure of work-item `id` (the value RenderImage blends in, renderer.cl:491)

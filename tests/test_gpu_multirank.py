@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir, frames_in_flight=1):
+def _worker(rank, world, port, tmpdir, frames_in_flight=1, backend="gloo"):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -34,12 +34,17 @@ def _worker(rank, world, port, tmpdir, frames_in_flight=1):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo: every rank on cuda:0 (single-GPU box); nccl == RCCL: one rank per device
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = scenes.build("metal_3spp")
     fr = multigpu.FrameRenderer(sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"], sc["w"], rank=rank,
-                                world=world, device=torch.device("cuda", 0),
-                                frames_in_flight=frames_in_flight)
+                                world=world, device=dev, frames_in_flight=frames_in_flight)
     for _ in range(2 * frames_in_flight + 1):  # every slot reused at least once
         d_px, d_argb = fr.render()
     torch.cuda.synchronize()
@@ -62,3 +67,21 @@ def test_tile_partition_over_ranks(tmp_path, oracle_mod, world, frames_in_flight
     argb = np.load(tmp_path / "argb.npy")
     assert np.array_equal(px.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(argb, want_argb)
+
+
+@pytest.mark.parametrize("frames_in_flight", [1, 2])
+def test_tile_partition_over_rccl(tmp_path, oracle_mod, frames_in_flight):
+    """The same with one rank per GPU and the gather on the `nccl` backend (= RCCL over xGMI),
+    side streams included -- the path bench.py --gpus N takes.  Needs >= 2 devices: runs on the
+    driver's multi-GPU node, skipped on the single-GPU box."""
+    import scenes
+
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip(f"{world} device(s): RCCL cannot place two ranks on one GPU")
+    world = min(world, 8)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), frames_in_flight, "nccl"), nprocs=world, join=True)
+    sc = scenes.build("metal_3spp")
+    want, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    assert np.array_equal(np.load(tmp_path / "px.npy").view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "argb.npy"), want_argb)

@@ -29,7 +29,8 @@ def main():
     from raymarchcl_amd import _native, generators as gen, materials, structs
 
     rng = np.random.default_rng(args.seed)
-    vols = [("gyroid", 64), ("terrain", 64), ("blobs", 64), ("gyroid-crop", (64, 40, 48)), ("gyroid", 32)]
+    vols = [("gyroid", 64), ("terrain", 64), ("blobs", 64), ("gyroid-crop", (64, 40, 48)), ("gyroid", 32),
+            ("gyroid", 128), ("gyroid", 256), ("terrain", 128)]
     sparse = gen.make_blob_volume(64, radius=(0.01, 0.03))
     mats = sorted(materials.presets)
     bad = 0
@@ -38,7 +39,7 @@ def main():
         kind, vres = vols[int(rng.integers(len(vols)))]
         vox = sparse if (kind == "blobs" and rng.random() < 0.5) else scenes.volume(kind, vres)
         vres3 = [vres] * 3 if isinstance(vres, int) else list(vres)
-        w, h, it = int(rng.integers(17, 64)), int(rng.integers(9, 48)), int(rng.choice([1, 2, 4]))
+        w, h, it = int(rng.integers(17, 64)), int(rng.integers(9, 48)), int(rng.choice([1, 2, 4, 3, 8, 16]))
         inside = rng.random() < 0.25
         eye = (rng.uniform(-0.9, 0.9, 3) if inside else
                rm.compute_eyepos(rng.uniform(0, 360), rng.uniform(1.2, 3.5), rng.uniform(-0.9, 1.6)))
@@ -57,6 +58,25 @@ def main():
                         fogPow=float(rng.uniform(0, 0.2)), numLights=int(rng.integers(1, 3)))
             for k in rng.choice(sorted(pool), size=int(rng.integers(1, 5)), replace=False):
                 over[str(k)] = pool[str(k)]
+        if rng.random() < 0.3:
+            # the box the byte grid occupies: anisotropic scale, shifted / asymmetric clip planes,
+            # a march that starts away from the eye (the exact-skip arguments read all of these)
+            sc3 = rng.uniform(0.7, 1.4, 3)
+            kind_box = int(rng.integers(0, 4))
+            if kind_box in (0, 3):
+                over.update(voxelBounds=[float(v) for v in sc3], voxelBounds2=[float(2 * v) for v in sc3],
+                            invVoxelScale=[float(0.5 / v) for v in sc3],
+                            voxelBoundsMin=[float(-0.99 * v) for v in sc3], voxelBoundsMax=[float(0.99 * v) for v in sc3])
+            if kind_box in (1, 3):
+                lo = rng.uniform(-0.99, -0.3, 3)
+                hi = rng.uniform(0.3, 0.99, 3)
+                b = over.get("voxelBounds", [1.0, 1.0, 1.0])
+                over.update(voxelBoundsMin=[float(l * bb) for l, bb in zip(lo, b)],
+                            voxelBoundsMax=[float(hh * bb) for hh, bb in zip(hi, b)])
+            if kind_box in (2, 3):
+                over["startDist"] = float(rng.uniform(0.0, 1.5))
+            if rng.random() < 0.3:
+                over["up"] = [float(v) for v in rng.normal(size=3)]
         recs = []
         for i in range(it):
             o = rm.render_options(t=i * 0.333, **base)
