@@ -76,15 +76,34 @@ def build_inputs(wl):
     return vox, (vres,) * 3, opts, mc
 
 
+def source_digest():
+    """Digest of everything the hot kernel is compiled from (sources + flags): identifies the build
+    a PMC measurement belongs to."""
+    import hashlib
+
+    from raymarchcl_amd import _native
+
+    h = hashlib.sha256(" ".join(_native.HIPCC_FLAGS).encode())
+    for name in sorted(os.listdir(_native.CSRC)):
+        h.update(name.encode())
+        h.update(open(os.path.join(_native.CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(path):
-    """HBM bytes per render-pass launch from a committed rocprofv3 --pmc
-    summary (profiles/*.json written by tools/pmc_summary.py), or None."""
-    if path and os.path.exists(path):
-        try:
-            return json.load(open(path)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+    """HBM bytes per launch of the frame kernel from a rocprofv3 --pmc run (tools/pmc_traffic.sh
+    writes the JSON together with the digest of the sources it measured).  Reported only when
+    that digest is the one of the library being benchmarked: a number measured on another build
+    says nothing about this one.  -> (bytes or None, note)"""
+    if not (path and os.path.exists(path)):
+        return None, "no PMC measurement on file"
+    try:
+        j = json.load(open(path))
+    except Exception:
+        return None, "unreadable PMC file"
+    if j.get("source_digest") != source_digest():
+        return None, f"PMC file {os.path.basename(path)} was measured on another build ({j.get('source_digest')})"
+    return j.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this build ({os.path.basename(path)})"
 
 
 def main():
@@ -98,7 +117,7 @@ def main():
                          "default 3 on one GPU, 2 per rank on several -- measured best)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -168,19 +187,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # Dominant kernel: render_samples_kernel.  HIP events bracket its launch(es) of a
-    # frame on the stream they run on (torch's current stream, handed to the library);
-    # measured on extra frames right after the timed region so the event reads do not
-    # perturb it.
-    # (one frame at a time here: overlapped frames would stretch each other's launch)
+    # Dominant kernel: render_frame_kernel.  HIP events bracket its launch(es) of a frame on the
+    # stream they run on (the slot's stream, handed to the library); measured on extra frames
+    # right after the timed region so the event reads do not perturb it -- strictly one frame at
+    # a time (overlapped frames stretch each other's launch).  The same frames give the serial
+    # wall time per frame: what a caller of the blocking pipeline (core.clj:171) sees.
     launches = 1
-    for _ in range(5):
-        torch.cuda.synchronize(dev)
+    serial = []
+    for _ in range(6):
+        sync_all()
         fr.frame = 0
+        ts = time.perf_counter()
         fr.render()
+        sync_all()
+        serial.append((time.perf_counter() - ts) * 1e3)
         ms, launches = fr.ctx.last_frame_timing()
         kernel_ms.append(ms / launches)
     pass_ms = float(np.median(kernel_ms))  # average duration of one render-kernel launch
+    serial_ms = float(np.median(serial[1:]))
 
     out = None
     if rank == 0:
@@ -201,7 +225,8 @@ def main():
         # one launch covers spp/launches passes of this rank's tiles
         alg_bytes_launch = alg_bytes_frame / launches / world
         achieved = alg_bytes_launch / (pass_ms * 1e-3) / 1e9
-        traffic = load_traffic(args.traffic) if (world == 1 and args.workload == "c2") else None
+        traffic, traffic_note = (load_traffic(args.traffic) if (world == 1 and args.workload == "c2")
+                                 else (None, "measured for the default workload on one GPU only"))
         out = {
             "metric": "Mrays/s (primary rays = pixel samples per second) + ms/frame, " +
                       ("256^3 gyroid 1280x720x16spp" if args.workload == "c2" else wl["desc"]),
@@ -211,6 +236,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_frame_serial": round(serial_ms, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -219,11 +245,15 @@ def main():
             "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]],
                        "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + ((", gloo gather through the host (BENCH_ONE_DEVICE rehearsal: all ranks on one GPU)" if rehearsal
                                      else ", RCCL gather to rank 0") if world > 1 else ""),
-                       "frames_in_flight": len(fr.slots)},
+                       "frames_in_flight": len(fr.slots),
+                       "overlap": ("none: frames are strictly serial" if len(fr.slots) == 1 else
+                                   f"ms_per_step is the frame period with {len(fr.slots)} successive frames in flight "
+                                   "on separate HIP streams (the tail of one launch overlaps the head of the "
+                                   "next); ms_per_frame_serial and roofline.kernel_ms are one frame alone")},
             "all_rays_per_s_M": round((c["rays"] + c["ao_calls"]) * args.steps / elapsed / 1e6, 2),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "render_frame_kernel<accel, %s waves/SIMD>" % os.environ.get("RAYMARCH_WAVES_PER_SIMD", "7"), "kernel_ms": round(pass_ms, 4),
                 "launches_per_frame": launches,
                 "alg_bytes_per_launch": int(alg_bytes_launch),
@@ -240,11 +270,13 @@ def main():
             # once per (volume, isoVal), outside every timed region: the tables derived from the
             # volume (dist8, oct8, surf32) -- reported so that nothing is hidden in the set-up
             tp = time.perf_counter()
-            hctx.debug_get_accel(opts[284])
-            out["precompute"] = {"derived_tables_ms": round((time.perf_counter() - tp) * 1e3, 2),
-                                 "note": "dist8 + oct8 + surf32 of the resident volume incl. copy-out for this "
-                                         "measurement; built once per (volume, isoVal), not per frame"}
-            hctx.render_frame(opts, mc, n)
+            hctx.render_frame(opts, mc, n)  # the first frame of a fresh context builds the tables
+            first_ms = (time.perf_counter() - tp) * 1e3
+            out["precompute"] = {"derived_tables_ms": round(hctx.last_table_build_ms(), 3),
+                                 "first_frame_ms": round(first_ms, 3),
+                                 "note": "dist8 + oct8 + surf32 of the resident volume (device time, HIP events), built "
+                                         "once per (volume, isoVal) inside the first frame that needs them; "
+                                         "first_frame_ms = that frame through the host-buffer boundary, tables included"}
             th = time.perf_counter()
             for _ in range(3):
                 hctx.render_frame(opts, mc, n)
@@ -306,8 +338,10 @@ def cpu_baseline(vox, opts, mc, n, spp, passes):
         ref_dt = min(run_reference(), run_reference())
         out["reference_build"] = {
             "value": round(n * passes / ref_dt / 1e6, 4),
-            "note": "unmodified renderer.cl compiled for x86-64 (oracle/_ref), same sample and threads; "
-                    "its OpenCL built-ins are out-of-line calls into a shim"}
+            "note": "unmodified renderer.cl compiled for x86-64, same sample and threads; its OpenCL built-ins "
+                    "are out-of-line calls into a shim.  PREBUILT in the build container (oracle/_ref is "
+                    "git-ignored and travels with the snapshot): a clean clone without /root/reference "
+                    "reports only the port"}
     except Exception:
         pass
     return out
