@@ -120,76 +120,106 @@ __global__ __launch_bounds__(256) void surf_kernel(const uint8_t* __restrict__ v
 // signs, so the samples it may skip are exactly those of dist8's rule with d := n
 // (n >= d always).  0 = hit cell, capped at 255.
 //
-// Built from a summed-volume table of the hit mask (box sum == 0 <=> box empty) by
-// bisection on n: 8 steps x 8 reads per (cell, octant).
-__global__ __launch_bounds__(256) void sat_x_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
-                                                    uint32_t* __restrict__ sat) {
-  // sat has (rx+1, ry+1, rz+1) entries; entry (x,y,z) = number of hit cells in [0,x) x [0,y) x [0,z)
-  const long long rows = (long long)(d.ry + 1) * (d.rz + 1);
-  const long long sx = d.rx + 1;
-  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
-       r += (long long)gridDim.x * blockDim.x) {
-    const int y = (int)(r % (d.ry + 1)), z = (int)(r / (d.ry + 1));
-    uint32_t* row = sat + r * sx;
-    uint32_t acc = 0;
-    row[0] = 0;
-    if (y == 0 || z == 0) {
-      for (int x = 1; x <= d.rx; x++) row[x] = 0;
-      continue;
-    }
-    const uint8_t* src = vox + ((long long)(z - 1) * d.ry + (y - 1)) * d.rx;
-    for (int x = 1; x <= d.rx; x++) {
-      acc += src[x - 1] > iso ? 1u : 0u;
-      row[x] = acc;
-    }
-  }
-}
-__global__ __launch_bounds__(256) void sat_axis_kernel(uint32_t* __restrict__ sat, Dim d, int axis) {
-  const long long sx = d.rx + 1, sy = d.ry + 1, sz = d.rz + 1;
-  const long long lines = axis == 1 ? sx * sz : sx * sy;
-  for (long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x; l < lines;
-       l += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(l % sx);
-    const long long o = l / sx;  // z (axis 1) or y (axis 2)
-    long long base, stride;
-    int len;
-    if (axis == 1) { base = (o * sy) * sx + x; stride = sx; len = (int)sy; }
-    else { base = o * sx + x; stride = sx * sy; len = (int)sz; }
-    uint32_t acc = 0;
-    for (int k = 0; k < len; k++) {
-      acc += sat[base + k * stride];
-      sat[base + k * stride] = acc;
-    }
-  }
-}
-__device__ __forceinline__ uint32_t sat_box(const uint32_t* __restrict__ sat, const Dim& d, int x0,
-                                            int x1, int y0, int y1, int z0, int z1) {
-  // hit cells in [x0,x1) x [y0,y1) x [z0,z1)
-  const long long sx = d.rx + 1, sxy = sx * (d.ry + 1);
-#define RM_S(X, Y, Z) sat[(long long)(Z) * sxy + (long long)(Y) * sx + (X)]
-  return RM_S(x1, y1, z1) - RM_S(x0, y1, z1) - RM_S(x1, y0, z1) - RM_S(x1, y1, z0) + RM_S(x0, y0, z1) +
-         RM_S(x0, y1, z0) + RM_S(x1, y0, z0) - RM_S(x0, y0, z0);
-#undef RM_S
-}
-__global__ __launch_bounds__(256) void oct_kernel(const uint32_t* __restrict__ sat, Dim d,
-                                                  uint8_t* __restrict__ out8) {
+// Built by dynamic programming: the cube of edge n at q is empty iff q is empty and the seven
+// cubes of edge n-1 at q + s*(dx,dy,dz), (dx,dy,dz) in {0,1}^3 \\ 0, are (together with q they
+// cover it), so  n(q) = hit(q) ? 0 : 1 + min over those seven neighbours AHEAD of n, with 0 for
+// neighbours beyond the grid.  With u = per-axis distance to the grid face ahead, a cell depends
+// on cells with smaller u only.  The grid is cut into 16^3-cell tiles in u-space; a workgroup
+// sweeps one tile plane by plane (u_x + u_y + u_z = const: 46 steps of at most 256 independent
+// cells, one per thread), and the tiles on a tile diagonal -- independent of each other -- form
+// one launch, all eight octants in it (each in its own mirrored frame): 3 * R/16 launches.  The
+// tile and the finished layer ahead of it are staged in LDS (17^3 bytes), the sweep runs there.  (Round 1 bisected on a summed-volume table: 64 uint32 reads
+// per (cell, octant) and 4.3 GiB of scratch at 1024^3; one launch per cell plane -- 766 at 256^3 --
+// is bound by launch latency: 12 ms.)
+constexpr int kOctTile = 16;
+constexpr int kOctLds = kOctTile + 1;  // + the layer of cells ahead of the tile (u - 1)
+__global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
+                                                       uint8_t* __restrict__ out8, int k, int a_lo, int nb, int nc) {
+  // the tile and the layer of cells ahead of it, in u-space: s[lc + 1][lb + 1][la + 1]
+  __shared__ uint8_t s[kOctLds * kOctLds * kOctLds];
+  const int o = blockIdx.y;                       // octant
+  const bool nx = o & 1, ny = o & 2, nz = o & 4;  // bit set: walking towards the low face
+  // tile (A, B, C) of this block on the tile diagonal A + B + C = k
+  const int A = a_lo + (int)(blockIdx.x / nb), B = (int)(blockIdx.x % nb), C = k - A - B;
+  if (C < 0 || C >= nc) return;
   const long long total = (long long)d.rx * d.ry * d.rz;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total * 8;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int o = (int)(i / total);
-    const long long c = i % total;
-    const int x = (int)(c % d.rx), y = (int)((c / d.rx) % d.ry), z = (int)(c / ((long long)d.rx * d.ry));
-    const bool nx = o & 1, ny = o & 2, nz = o & 4;
-    // room to the grid edge ahead, per axis (cells including q itself)
-    int hi = min(255, min(nx ? x + 1 : d.rx - x, min(ny ? y + 1 : d.ry - y, nz ? z + 1 : d.rz - z)));
-    int lo = 0;  // largest n known empty
-    while (lo < hi) {
-      const int n = (lo + hi + 1) >> 1;
-      const int x0 = nx ? x - n + 1 : x, y0 = ny ? y - n + 1 : y, z0 = nz ? z - n + 1 : z;
-      if (sat_box(sat, d, x0, x0 + n, y0, y0 + n, z0, z0 + n) == 0) lo = n;
-      else hi = n - 1;
+  const long long sy = d.rx, sz = (long long)d.rx * d.ry;
+  uint8_t* __restrict__ tab = out8 + (long long)o * total;
+  const int a0 = A * kOctTile, b0 = B * kOctTile, c0 = C * kOctTile;
+  // fill: tile cells get 255 (empty, edge unknown) or 0 (hit, or behind the grid's far face);
+  // the layer ahead gets the finished values of the neighbouring tiles, 0 beyond the grid
+  for (int i = threadIdx.x; i < kOctLds * kOctLds * kOctLds; i += 256) {
+    const int la = i % kOctLds - 1, lb = (i / kOctLds) % kOctLds - 1, lc = i / (kOctLds * kOctLds) - 1;
+    const int a = a0 + la, b = b0 + lb, c = c0 + lc;  // u
+    uint8_t v = 0;
+    if (a >= 0 && b >= 0 && c >= 0 && a < d.rx && b < d.ry && c < d.rz) {
+      const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
+      const long long q = (long long)z * sz + (long long)y * sy + x;
+      if (la < 0 || lb < 0 || lc < 0) v = tab[q];  // finished by an earlier launch
+      else v = vox[q] <= iso ? 255 : 0;
     }
-    out8[i] = (uint8_t)lo;
+    s[i] = v;
+  }
+  __syncthreads();
+  const int la = threadIdx.x & (kOctTile - 1), lb = threadIdx.x >> 4;
+  for (int t = 0; t < 3 * kOctTile - 2; t++) {
+    const int lc = t - la - lb;
+    if (lc >= 0 && lc < kOctTile) {
+      const int i = ((lc + 1) * kOctLds + (lb + 1)) * kOctLds + (la + 1);
+      if (s[i]) {
+        const int e1 = 1, e2 = kOctLds, e3 = kOctLds * kOctLds;
+        int m = s[i - e1];
+        m = min(m, (int)s[i - e2]);
+        m = min(m, (int)s[i - e3]);
+        m = min(m, (int)s[i - e1 - e2]);
+        m = min(m, (int)s[i - e1 - e3]);
+        m = min(m, (int)s[i - e2 - e3]);
+        m = min(m, (int)s[i - e1 - e2 - e3]);
+        s[i] = (uint8_t)min(255, m + 1);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < kOctTile * kOctTile * kOctTile; i += 256) {
+    const int la2 = i & (kOctTile - 1), lb2 = (i >> 4) & (kOctTile - 1), lc2 = i >> 8;
+    const int a = a0 + la2, b = b0 + lb2, c = c0 + lc2;
+    if (a < d.rx && b < d.ry && c < d.rz) {
+      const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
+      tab[(long long)z * sz + (long long)y * sy + x] = s[((lc2 + 1) * kOctLds + (lb2 + 1)) * kOctLds + (la2 + 1)];
+    }
+  }
+}
+
+// A/B (-DRM_COARSE=1, not the default): per 4x4x4-cell block the SMALLEST value of each of the
+// nine tables -- a lower bound of every cell's value in the block, hence a valid (shorter) skip
+// distance.  (R/4)^3 bytes per table: 2.4 MB for nine tables at 256^3, resident in every XCD's L2.
+__global__ __launch_bounds__(256) void coarse_kernel(const uint8_t* __restrict__ tabs, Dim d, int ntab,
+                                                     uint8_t* __restrict__ coarse) {
+  const int bx = (d.rx + 3) >> 2, by = (d.ry + 3) >> 2, bz = (d.rz + 3) >> 2;
+  const long long blocks = (long long)bx * by * bz, total = (long long)d.rx * d.ry * d.rz;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < blocks * ntab;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / blocks);
+    const long long b = i % blocks;
+    const int x0 = (int)(b % bx) * 4, y0 = (int)((b / bx) % by) * 4, z0 = (int)(b / ((long long)bx * by)) * 4;
+    int m = 255;
+    for (int z = z0; z < min(z0 + 4, d.rz); z++)
+      for (int y = y0; y < min(y0 + 4, d.ry); y++)
+        for (int x = x0; x < min(x0 + 4, d.rx); x++)
+          m = min(m, (int)tabs[(long long)t * total + ((long long)z * d.ry + y) * d.rx + x]);
+    coarse[i] = (uint8_t)m;
+  }
+}
+
+// dist8 from the eight directional tables: the nearest obstacle lies in one of the closed
+// octants around the cell, so the Chebyshev distance is the smallest of the eight cube edges
+__global__ __launch_bounds__(256) void dist_from_oct_kernel(const uint8_t* __restrict__ oct8, long long total,
+                                                            uint8_t* __restrict__ dist) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int m = oct8[i];
+    for (int o = 1; o < 8; o++) m = min(m, (int)oct8[(long long)o * total + i]);
+    dist[i] = (uint8_t)m;
   }
 }
 
@@ -227,17 +257,33 @@ hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz)
   return hipGetLastError();
 }
 
-size_t octant_scratch_bytes(int rx, int ry, int rz) { return (size_t)(rx + 1) * (ry + 1) * (rz + 1) * 4; }
-
+// d_dist9: table 0 = dist8 (written here from the octants), tables 1..8 = the directional ones
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
-                         uint8_t* d_dist9, uint32_t* d_sat) {
+                         uint8_t* d_dist9) {
   const Dim d{rx, ry, rz};
   const long long total = (long long)rx * ry * rz;
-  auto blocks_for = [](long long n) { return (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256); };
-  sat_x_kernel<<<blocks_for((long long)(ry + 1) * (rz + 1)), 256, 0, st>>>(d_vox, d, iso, d_sat);
-  sat_axis_kernel<<<blocks_for((long long)(rx + 1) * (rz + 1)), 256, 0, st>>>(d_sat, d, 1);
-  sat_axis_kernel<<<blocks_for((long long)(rx + 1) * (ry + 1)), 256, 0, st>>>(d_sat, d, 2);
-  oct_kernel<<<blocks_for(total * 8), 256, 0, st>>>(d_sat, d, d_dist9 + total);
+  uint8_t* oct = d_dist9 + total;
+  const int na = (rx + kOctTile - 1) / kOctTile, nb = (ry + kOctTile - 1) / kOctTile,
+            nc = (rz + kOctTile - 1) / kOctTile;
+  for (int k = 0; k < na + nb + nc - 2; k++) {
+    // tile columns A that hold a tile of this diagonal (B and C range over their whole extent)
+    const int a_lo = max(0, k - (nb - 1) - (nc - 1)), a_hi = min(na - 1, k);
+    if (a_hi < a_lo) continue;
+    const dim3 grid((unsigned)((a_hi - a_lo + 1) * nb), 8u);
+    oct_tile_kernel<<<grid, 256, 0, st>>>(d_vox, d, iso, oct, k, a_lo, nb, nc);
+  }
+  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  dist_from_oct_kernel<<<blocks, 256, 0, st>>>(oct, total, d_dist9);
+  return hipGetLastError();
+}
+
+long long coarse_bytes(int rx, int ry, int rz, int ntab) {
+  return (long long)((rx + 3) >> 2) * ((ry + 3) >> 2) * ((rz + 3) >> 2) * ntab;
+}
+hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, int rz, int ntab, uint8_t* d_coarse) {
+  const long long n = coarse_bytes(rx, ry, rz, ntab);
+  const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  coarse_kernel<<<blocks, 256, 0, st>>>(d_tabs, Dim{rx, ry, rz}, ntab, d_coarse);
   return hipGetLastError();
 }
 
@@ -246,9 +292,11 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
   const Dim d{rx, ry, rz};
   const long long total = (long long)rx * ry * rz;
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  dist_x_kernel<<<blocks, 256, 0, st>>>(d_vox, d, iso, d_dist);
-  dist_axis_kernel<<<blocks, 256, 0, st>>>(d_dist, d, 1, d_tmp);
-  dist_axis_kernel<<<blocks, 256, 0, st>>>(d_tmp, d, 2, d_dist);
+  if (d_dist) {  // dist8 alone by separable passes (when the directional tables are not built)
+    dist_x_kernel<<<blocks, 256, 0, st>>>(d_vox, d, iso, d_dist);
+    dist_axis_kernel<<<blocks, 256, 0, st>>>(d_dist, d, 1, d_tmp);
+    dist_axis_kernel<<<blocks, 256, 0, st>>>(d_tmp, d, 2, d_dist);
+  }
   surf_kernel<<<blocks, 256, 0, st>>>(d_vox, d, iso, d_surf);
   return hipGetLastError();
 }

@@ -68,7 +68,7 @@ struct Volume {
   std::mutex mu;
   int device = 0;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
-  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf, sat_buf;
+  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf, coarse_buf;
   int rx = 0, ry = 0, rz = 0;
   int accel_iso = -1;              // isoVal the tables were built for, -1 = stale
   unsigned long long oct_stride = 0;
@@ -76,7 +76,7 @@ struct Volume {
   double accel_build_ms = 0.0;     // wall time of the last table build (reported by bench.py)
   ~Volume() {
     (void)hipSetDevice(device);
-    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release(); sat_buf.release();
+    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release(); coarse_buf.release();
   }
 };
 
@@ -92,6 +92,7 @@ struct rm_ctx {
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
   int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most
+  int pack_waste = 15;       // RAYMARCH_PACK_WASTE: % of lane turns a partial last group may leave idle
   int waves_per_simd = 7;    // RAYMARCH_WAVES_PER_SIMD (4..8): register budget of the frame kernel
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   // records validated by rm_check_device_opts
@@ -165,18 +166,23 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     HIP_TRY(hipEventCreate(&t1));
     HIP_TRY(v.dist_buf.reserve(vox * tables));
     uint8_t* lin = static_cast<uint8_t*>(v.dist_buf.p);
-    HIP_TRY(v.tmp_buf.reserve(vox));
     HIP_TRY(v.surf_buf.reserve(vox * 4));
     HIP_TRY(hipEventRecord(t0, c->stream));
-    HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
-                             static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
     v.oct_stride = 0;
     if (oct) {
-      HIP_TRY(v.sat_buf.reserve(rmk::octant_scratch_bytes(v.rx, v.ry, v.rz)));
-      HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
-                                 static_cast<uint32_t*>(v.sat_buf.p)));
+      HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, nullptr, nullptr,
+                               static_cast<uint32_t*>(v.surf_buf.p)));
+      HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin));
       v.oct_stride = vox;
+    } else {
+      HIP_TRY(v.tmp_buf.reserve(vox));
+      HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
+                               static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
     }
+#if RM_COARSE
+    HIP_TRY(v.coarse_buf.reserve((size_t)rmk::coarse_bytes(v.rx, v.ry, v.rz, tables)));
+    HIP_TRY(rmk::build_coarse(c->stream, lin, v.rx, v.ry, v.rz, tables, static_cast<uint8_t*>(v.coarse_buf.p)));
+#endif
     HIP_TRY(hipEventRecord(t1, c->stream));
     // contexts that share the volume run on other streams: the tables are complete before
     // anybody else can see accel_iso
@@ -191,6 +197,9 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   out->oct_stride = v.oct_stride;
   out->dist = static_cast<const uint8_t*>(v.dist_buf.p);
   out->surf = static_cast<const uint32_t*>(v.surf_buf.p);
+#if RM_COARSE
+  out->coarse = static_cast<const uint8_t*>(v.coarse_buf.p);
+#endif
   return RM_OK;
 }
 
@@ -287,7 +296,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.resx = resx; f.n = n; f.passes = i1 - i0;
     f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
     f.min_waves = c->waves_per_simd;
-    f.pp_log2 = rmk::choose_pass_pack(i1 - i0, c->pass_pack);
+    f.pp_log2 = rmk::choose_pass_pack(i1 - i0, c->pass_pack, c->pack_waste);
     f.xcd_rows = c->xcd_rows;
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
@@ -374,6 +383,8 @@ static int create_one(int device_id, rm_ctx** out) {
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) c->pass_pack = atoi(pk);
+  const char* pw = getenv("RAYMARCH_PACK_WASTE");
+  if (pw && atoi(pw) >= 0 && atoi(pw) <= 100) c->pack_waste = atoi(pw);
   const char* sw = getenv("RAYMARCH_WAVES_PER_SIMD");
   if (sw && atoi(sw) >= 4 && atoi(sw) <= 8) c->waves_per_simd = atoi(sw);
   *out = c;

@@ -13,12 +13,18 @@ inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / p
 int tiles_total(int resx, int n);
 void dump_work_stats();  // no-op unless built with -DRM_WORK_STATS
 
+#ifndef RM_COARSE
+#define RM_COARSE 0  // A/B: consult a 4^3-block minimum of the tables before the fine fetch (host and device agree)
+#endif
 struct Accel {  // nullptrs = not available: the kernels then run the plain fixed-step march
   const uint8_t* dist = nullptr;
   const uint32_t* surf = nullptr;
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
   unsigned long long oct_stride = 0;
+  const uint8_t* coarse = nullptr;  // RM_COARSE: block minima of the 1 or 9 tables, table-major
 };
+long long coarse_bytes(int rx, int ry, int rz, int ntab);
+hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, int rz, int ntab, uint8_t* d_coarse);
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
@@ -41,21 +47,20 @@ struct FrameLaunch {
   bool xcd_rows = true, accumulate = false, row_major = false;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
-int choose_pass_pack(int passes, int max_log2);
+int choose_pass_pack(int passes, int max_log2, int waste_pct = 15);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
                           const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
                           uint32_t* d_argb, int n);
-// dist8 / surf32 of a resident volume for hit threshold `iso` (rm_accel.hip);
-// d_tmp is scratch of the volume's size.
+// surf32 of a resident volume for hit threshold `iso` (rm_accel.hip) and -- when d_dist is not
+// null -- dist8 alone by separable passes (d_tmp: scratch of the volume's size)
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                        uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf);
-// the 8 directional tables behind dist8 (d_dist9 = 9 * volume bytes, table 0 = dist8 itself);
-// d_sat is scratch of octant_scratch_bytes()
-size_t octant_scratch_bytes(int rx, int ry, int rz);
+// the 8 directional tables (d_dist9 = 9 * volume bytes: tables 1..8) and dist8 derived from
+// them (table 0); no scratch
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
-                         uint8_t* d_dist9, uint32_t* d_sat);
+                         uint8_t* d_dist9);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // rm_volgen.hip: the other volume producers of the reference, on the device
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);

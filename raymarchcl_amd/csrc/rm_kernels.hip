@@ -121,6 +121,7 @@ struct FrameArgs {
   const uint32_t* __restrict__ surf32;
   unsigned long long oct_stride;
   const float* __restrict__ sdf;
+  const uint8_t* __restrict__ coarse;  // RM_COARSE A/B
   const float4* __restrict__ mc_all;   // scatter table of the launch's first pass
   const RmOpts* __restrict__ opts_all; // record of the launch's first pass
   const RmOpts* __restrict__ opts0;    // record 0 of the frame (TonemapImage reads its gamma)
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
     const bool live = pass < a.passes;
 #endif
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
-    rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
+    rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf, a.coarse};
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
@@ -411,12 +412,12 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
 }
 
 // log2 of the passes per wavefront for a run of `passes` records that differ in .time only:
-// the largest k <= max_log2 whose last group leaves at most ~15 % of the lane turns without a
-// pass (k = 0 never leaves any)
-int choose_pass_pack(int passes, int max_log2) {
+// the largest k <= max_log2 whose last group leaves at most waste_pct % of the lane turns
+// without a pass (k = 0 never leaves any)
+int choose_pass_pack(int passes, int max_log2, int waste_pct) {
   for (int k = max_log2; k >= 1; k--) {
     const int pp = 1 << k;
-    if ((double)(((passes + pp - 1) / pp) * pp) <= 1.15 * (double)passes) return k;
+    if ((double)(((passes + pp - 1) / pp) * pp) * 100.0 <= (100.0 + waste_pct) * (double)passes) return k;
   }
   return 0;
 }
@@ -445,6 +446,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.surf32 = f.accel.surf;
   a.oct_stride = f.accel.oct_stride;
   a.sdf = f.sdf;
+  a.coarse = f.accel.coarse;
   a.mc_all = reinterpret_cast<const float4*>(f.mc_all);
   a.opts_all = f.opts_all;
   a.opts0 = f.opts0;

@@ -55,7 +55,14 @@ struct Scene {
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
   unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
   const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
+  const uint8_t* __restrict__ coarse = nullptr;  // RM_COARSE A/B: 4^3-block minima of the tables
 };
+#ifndef RM_COARSE
+#define RM_COARSE 0
+#endif
+#ifndef RM_COARSE_MIN
+#define RM_COARSE_MIN 6  // a block minimum of at least this many cells is used without the fine fetch
+#endif
 
 // ---- leaf routines; `o` points at the option record in device memory ----
 
@@ -142,7 +149,8 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // j = 1 + floor(0.98 * (d-1) / s)   (inv_s = 0.98 / s; the 2 % absorb the <= 0.01
 // cell of accumulated rounding drift and the rounding of p*res).
 RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
-                     float inv_s, int* cell_out, unsigned long long table_off = 0, unsigned int* dhist = nullptr) {
+                     float inv_s, int* cell_out, unsigned long long table_off = 0, unsigned int* dhist = nullptr,
+                     const uint8_t* __restrict__ coarse = nullptr, unsigned int coarse_off = 0) {
   const int qx = rmd::convert_int_sat(p.x * (float)o.voxelRes[0]);
   const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
   const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
@@ -151,7 +159,16 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
   const unsigned cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
                                  (unsigned)o.voxelRes[0]) + (unsigned)qx;
+#if RM_COARSE
+  // block minimum first (a lower bound of the cell's value: a shorter but valid skip); the
+  // fine table only where the bound is too small to be useful
+  const unsigned bx = ((unsigned)o.voxelRes[0] + 3u) >> 2, by = ((unsigned)o.voxelRes[1] + 3u) >> 2;
+  const unsigned blk = __umul24(__umul24((unsigned)qz >> 2, by) + ((unsigned)qy >> 2), bx) + ((unsigned)qx >> 2);
+  int d = coarse[coarse_off + blk];
+  if (d < RM_COARSE_MIN) d = dist8[cell + table_off];
+#else
   const int d = dist8[cell + table_off];
+#endif
   if (dhist) {  // stats build only
     dhist[d < 4 ? d : (d < 8 ? 4 : 5)]++;
     dhist[6] = (unsigned)d;
@@ -473,10 +490,16 @@ struct Tracer {
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
         // directional table of this walk (a walk never moves against the signs of delta)
         unsigned long long table_off = 0;  // 64-bit: nine 1024^3 tables span 9 GiB
+        unsigned int coarse_off = 0;
         if (sc.oct_stride) {
           const unsigned int oct = (delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u);
           table_off = (oct + 1u) * sc.oct_stride;
+#if RM_COARSE
+          coarse_off = (oct + 1u) * ((((unsigned)o.voxelRes[0] + 3u) >> 2) * (((unsigned)o.voxelRes[1] + 3u) >> 2) *
+                                     (((unsigned)o.voxelRes[2] + 3u) >> 2));
+#endif
         }
+        (void)coarse_off;
         RM_WS(ws_walks++);
         RM_WS(ws_k_walks[ws_kind]++);
         (void)s;
@@ -498,9 +521,9 @@ struct Tracer {
           RM_WS(ws_steps += (unsigned)steps);
           RM_WS(ws_nf++);
 #ifdef RM_WORK_STATS
-          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist);
+          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist, sc.coarse, coarse_off);
 #else
-          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off);
+          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, nullptr, sc.coarse, coarse_off);
 #endif
           RM_WS(ws_steps -= (unsigned)steps);
 #ifdef RM_WORK_STATS

@@ -5,7 +5,8 @@ thi.ng/structgen (core.clj:25-26) and encodes one struct per pass
 (core.clj:99-106).  structgen is un-vendored; the layout below is the one
 clang computes for the same typedef (renderer.cl:14-19, 35-78) under OpenCL
 alignment rules (float3 occupies 16 B) and is re-derived from the reference
-source by tests/test_layout.py whenever /root/reference is present.
+source by tests/test_oracle_vs_reference.py::test_layout_matches_reference_typedef whenever
+/root/reference is present (the C side asserts the same offsets statically: csrc/rm_opts.h).
 
 Encoding rules relied on by the reference call sites: little-endian, every
 number narrowed to float32 / int32 / uint8, missing keys encode as 0, short
