@@ -47,7 +47,7 @@ struct FrameLaunch {
   bool xcd_rows = true, accumulate = false, row_major = false;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
-int choose_pass_pack(int passes, int max_log2, int waste_pct = 15);
+int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
                           const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n);

@@ -1,29 +1,41 @@
 #!/bin/bash
 # Everything profiles/ holds for the current build, in one GPU call:
-#   kernel trace (rocprofv3 --kernel-trace --stats), the PMC passes, the traffic json,
-#   the default bench line and the other workloads.  Output -> gpurun_out/final/
-# (bench.py runs strictly serial frames under the profilers so that per-launch numbers
-#  are those of one launch; the bench line itself uses the default frames in flight.)
+#   kernel trace (rocprofv3 --kernel-trace --stats), the PMC passes, the traffic json (with the
+#   digest of the sources), the default bench line, the other workloads, the tile-partition
+#   timing, work statistics and the phase clock.  Output -> gpurun_out/final/
+# (bench.py runs strictly serial frames under the profilers so that per-launch numbers are those
+#  of one launch; the bench line itself uses the default frames in flight.)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > $OUT/kt.log 2>&1
 DB=$(find /tmp/kt -name "*_results.db" | head -1)
 python $R/tools/rocprof_summary.py $DB > $OUT/kernel_stats.txt 2>&1
 cd $R
 tools/pmc_run.sh final/pmc --steps 8 --warmup 2 --frames-in-flight 1 > $OUT/pmc_run.log 2>&1
 python tools/pmc_summary.py $OUT/pmc/p1/pmc_results.db $OUT/pmc/p2/pmc_results.db $OUT/pmc/p3/pmc_results.db \
-  $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel render_samples > $OUT/pmc.txt 2>&1
-python tools/pmc_summary.py $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel render_samples \
-  --traffic-json $R/profiles/r01_pmc_traffic.json > $OUT/traffic.log 2>&1
-cp $R/profiles/r01_pmc_traffic.json $OUT/pmc_traffic.json
+  $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel render_frame > $OUT/pmc.txt 2>&1
+python tools/pmc_summary.py $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel render_frame \
+  --traffic-json $OUT/pmc_traffic.json > $OUT/traffic.log 2>&1
+python - <<'PY'
+import json, os, sys
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R)
+import bench
+p = os.path.join(R, "gpurun_out", "final", "pmc_traffic.json")
+j = json.load(open(p))
+j["source_digest"] = bench.source_digest()
+json.dump(j, open(p, "w"), indent=1)
+# the bench line below reads it from profiles/
+json.dump(j, open(os.path.join(R, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
+PY
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 for w in c1 c3 c4 c5; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1; done > $OUT/other_workloads.txt
-RAYMARCH_OCTANTS=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_no_octants.json
 python tools/part_timing.py --frames-in-flight 2 --reps 30 > $OUT/part_timing.txt 2>&1
 python tools/work_stats.py c2 > $OUT/work_stats.txt 2>&1
 python tools/work_stats.py c2 --clock >> $OUT/work_stats.txt 2>&1
 python tools/sdf_bench.py > $OUT/sdf_bench.txt 2>&1
 rm -rf $OUT/pmc/p*/pmc_results.db
-head -c 600 $OUT/bench_line.json; echo; tail -3 $OUT/part_timing.txt; head -5 $OUT/kernel_stats.txt
+head -c 700 $OUT/bench_line.json; echo; tail -3 $OUT/part_timing.txt; head -6 $OUT/kernel_stats.txt
