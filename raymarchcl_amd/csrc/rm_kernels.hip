@@ -128,6 +128,7 @@ struct FrameArgs {
   float4* __restrict__ acc;            // tile-major partition accumulators, or the row-major image
   uint32_t* __restrict__ argb;         // row-major ARGB, or nullptr
   int n, resx, tile_first, tile_stride, tiles_per_part, pp_log2, passes, bpr;
+  long long total_blocks;              // RM_PERSISTENT: blocks of the frame (the grid is smaller)
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int row_major;                       // acc is indexed by work-item id instead of slot*64 + pixel
 };
@@ -145,8 +146,11 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 
 // MULTI = the launch holds more passes than a wavefront does (the loop over groups of passes
 // exists only then: a single group keeps nothing alive across the body of a sample)
-template <bool ACCEL, int MINW, bool SDFM, bool MULTI>
-__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
+#ifndef RM_PERSISTENT
+#define RM_PERSISTENT 0  // A/B: a resident grid whose wavefronts stride over the frame's blocks
+#endif
+template <bool ACCEL, bool SDFM, bool MULTI>
+__device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
   using Tr = rmk::Tracer<false, ACCEL, SDFM>;
   const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   // logical block of tile row 8*(m / bpr) + k, so XCD k renders every 8th tile ROW:
   // its primary rays sweep an eighth of the volume's slabs instead of all of them,
   // while rows stay interleaved finely enough to balance the load.
-  long long lb = blockIdx.x;
+  long long lb = hw_block;
   if (a.bpr > 0) {
     const long long m = lb >> 3, k = lb & 7;
     lb = ((m / a.bpr) * 8 + k) * a.bpr + (m % a.bpr);
@@ -176,10 +180,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   const int pix = zy * 8 + zx;  // 0..63 within the tile, row-major 8x8
   const int id = lane_pixel((int)tile, pix, a.resx, g.tiles_x, a.n, 0, a.n);
   if (id < 0) return;  // (all pp lanes of a pixel leave together)
-  static_assert(kWavesPerBlock == 1, "the LDS areas below belong to one wavefront");
   // (the colours of a group are exchanged through the area of the shared phases, whose posted
   //  values are dead once shade_wave() has returned)
-  __shared__ float wave_lds[ACCEL ? Tr::kWaveLdsFloats : 3 * 64];
   float* const blend_lds = wave_lds;
   const int pl = lane & (pp - 1);  // this lane's pass within a group
   const bool first = pl == 0;      // the lane that keeps its pixel's accumulator
@@ -261,6 +263,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
 #if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
   for (int k = 0; k < 64; k++)
     if (ws_acc[k]) atomicAdd(&g_work_stats[k], ws_acc[k]);
+#endif
+}
+
+template <bool ACCEL, int MINW, bool SDFM, bool MULTI>
+__global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
+  static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
+  __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
+#if RM_PERSISTENT
+  // (stride = grid size, a multiple of 8: a wavefront stays on the tile rows of its XCD)
+  for (long long b = blockIdx.x; b < a.total_blocks; b += gridDim.x) {
+    frame_block<ACCEL, SDFM, MULTI>(a, b, wave_lds);
+    __syncthreads();
+  }
+#else
+  frame_block<ACCEL, SDFM, MULTI>(a, blockIdx.x, wave_lds);
 #endif
 }
 
@@ -456,6 +473,16 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.tiles_per_part = tpp; a.pp_log2 = pp_log2; a.passes = f.passes; a.bpr = bpr;
   a.accumulate = f.accumulate ? 1 : 0;
   a.row_major = f.row_major ? 1 : 0;
+  a.total_blocks = blocks;
+#if RM_PERSISTENT
+  {  // as many one-wavefront workgroups as the chip holds at the kernel's occupancy
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long resident = (long long)cus * 4 * f.min_waves * RM_PERSISTENT;
+    if (blocks > resident) blocks = resident;
+  }
+#endif
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   const bool multi = f.passes > (1 << pp_log2);
 #define RM_FRAME(A, W, S)                                                    \

@@ -149,3 +149,26 @@ def test_c5_1024_volume_1080p_25spp(native, oracle_mod):
         px, argb = ctx.render_frame(opts, mc, n)
     ids = _sample_ids(n, w, 1000, 14, rows=(600,))
     _check_against_oracle(oracle_mod, vox, opts, mc, n, ids, px, argb)
+
+
+def test_launches_continue_each_others_accumulators(native, oracle_mod):
+    """A frame whose records change in the middle: 18 equal passes (two pass groups of one launch,
+    the second partial), one pass with another exposure, two passes with another isoVal (own
+    tables) -- three launches of the frame kernel, each continuing from the accumulator the
+    previous one left, the last one tonemapping."""
+    spec = dict(vol="gyroid", vres=64, w=44, h=36, iter=21, mat="metal2", theta=40, dist=2.3, dof=0.01)
+    sc = scenes.build(spec, mc_seed=900)
+    opts = bytearray(sc["opts"])
+    opts[18 * 544 + 260:18 * 544 + 264] = np.float32(1.7).tobytes()  # exposure of pass 18
+    for i in (19, 20):
+        opts[i * 544 + 284] = 90                                      # isoVal of the last two
+    opts = bytes(opts)
+    want, want_argb = oracle_mod.render_frame(sc["vox"], opts, sc["mc"], sc["n"])
+    for ranks in (1, 3):
+        with native.Context([0] * ranks if ranks > 1 else 0) as ctx:
+            ctx.set_volume(sc["vox"], sc["vres"])
+            px, argb = ctx.render_frame(opts, sc["mc"], sc["n"])
+            ms, launches = ctx.last_frame_timing()
+        assert launches == 3
+        assert _eq(px, want), (ranks, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
+        assert np.array_equal(argb, want_argb)

@@ -17,6 +17,7 @@ def analyse(lines, key):
         return
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     depth = 0
+    lanes = {}
     hist = {}
     n_ins = 0
     per_loop = {}
@@ -46,6 +47,9 @@ def analyse(lines, key):
         if not re.match(r"^\s+[a-z]", l):
             continue
         n_ins += 1
+        if "v_readlane_b32" in l or "v_writelane_b32" in l:
+            lanes.setdefault(depth, 0)
+            lanes[depth] += 1
         if "scratch_load" in l or "scratch_store" in l:
             k = "load" if "scratch_load" in l else "store"
             hist.setdefault(depth, {"load": 0, "store": 0})[k] += 1
@@ -55,6 +59,9 @@ def analyse(lines, key):
     print(f"{key}: {n_ins} instructions")
     for d in sorted(hist):
         print(f"  loop depth {d}: {hist[d]['load']} scratch loads, {hist[d]['store']} scratch stores")
+    if lanes:
+        print("  SGPR spill traffic (v_readlane / v_writelane) by depth: " +
+              ", ".join(f"{d}: {lanes[d]}" for d in sorted(lanes)))
     deep = sorted(((d, h, n) for (d, h), n in per_loop.items() if d >= 3), reverse=True)
     if deep:
         print("  loops at depth >= 3 with spills: " + ", ".join(f"{h}@{d}:{n}" for d, h, n in deep[:24]))
