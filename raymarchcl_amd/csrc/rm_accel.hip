@@ -131,10 +131,29 @@ __global__ __launch_bounds__(256) void surf_kernel(const uint8_t* __restrict__ v
 // tile and the finished layer ahead of it are staged in LDS (17^3 bytes), the sweep runs there.  (Round 1 bisected on a summed-volume table: 64 uint32 reads
 // per (cell, octant) and 4.3 GiB of scratch at 1024^3; one launch per cell plane -- 766 at 256^3 --
 // is bound by launch latency: 12 ms.)
+// index of cell (x, y, z) in a byte table: row-major, or 8x4x4-cell bricks of 128 B (x fastest
+// inside and between bricks)
+__device__ __forceinline__ long long tab_index(const Dim& d, int x, int y, int z, int bricked) {
+  if (!bricked) return ((long long)z * d.ry + y) * d.rx + x;
+  const long long nbx = (d.rx + 7) >> 3, nby = (d.ry + 3) >> 2;
+  const long long brick = ((long long)(z >> 2) * nby + (y >> 2)) * nbx + (x >> 3);
+  return (brick << 7) | (long long)(((z & 3) << 5) | ((y & 3) << 3) | (x & 7));
+}
+__global__ __launch_bounds__(256) void unbrick_kernel(const uint8_t* __restrict__ bricked, Dim d,
+                                                      uint8_t* __restrict__ lin) {
+  const long long total = (long long)d.rx * d.ry * d.rz;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % d.rx), y = (int)((i / d.rx) % d.ry), z = (int)(i / ((long long)d.rx * d.ry));
+    lin[i] = bricked[tab_index(d, x, y, z, 1)];
+  }
+}
+
 constexpr int kOctTile = 16;
 constexpr int kOctLds = kOctTile + 1;  // + the layer of cells ahead of the tile (u - 1)
 __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
-                                                       uint8_t* __restrict__ out8, int k, int a_lo, int nb, int nc) {
+                                                       uint8_t* __restrict__ out8, int k, int a_lo, int nb, int nc,
+                                                       long long table_bytes, int bricked) {
   // the tile and the layer of cells ahead of it, in u-space: s[lc + 1][lb + 1][la + 1]
   __shared__ uint8_t s[kOctLds * kOctLds * kOctLds];
   const int o = blockIdx.y;                       // octant
@@ -142,9 +161,8 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
   // tile (A, B, C) of this block on the tile diagonal A + B + C = k
   const int A = a_lo + (int)(blockIdx.x / nb), B = (int)(blockIdx.x % nb), C = k - A - B;
   if (C < 0 || C >= nc) return;
-  const long long total = (long long)d.rx * d.ry * d.rz;
   const long long sy = d.rx, sz = (long long)d.rx * d.ry;
-  uint8_t* __restrict__ tab = out8 + (long long)o * total;
+  uint8_t* __restrict__ tab = out8 + (long long)o * table_bytes;
   const int a0 = A * kOctTile, b0 = B * kOctTile, c0 = C * kOctTile;
   // fill: tile cells get 255 (empty, edge unknown) or 0 (hit, or behind the grid's far face);
   // the layer ahead gets the finished values of the neighbouring tiles, 0 beyond the grid
@@ -154,9 +172,8 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
     uint8_t v = 0;
     if (a >= 0 && b >= 0 && c >= 0 && a < d.rx && b < d.ry && c < d.rz) {
       const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
-      const long long q = (long long)z * sz + (long long)y * sy + x;
-      if (la < 0 || lb < 0 || lc < 0) v = tab[q];  // finished by an earlier launch
-      else v = vox[q] <= iso ? 255 : 0;
+      if (la < 0 || lb < 0 || lc < 0) v = tab[tab_index(d, x, y, z, bricked)];  // finished by an earlier launch
+      else v = vox[(long long)z * sz + (long long)y * sy + x] <= iso ? 255 : 0;
     }
     s[i] = v;
   }
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
     const int a = a0 + la2, b = b0 + lb2, c = c0 + lc2;
     if (a < d.rx && b < d.ry && c < d.rz) {
       const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
-      tab[(long long)z * sz + (long long)y * sy + x] = s[((lc2 + 1) * kOctLds + (lb2 + 1)) * kOctLds + (la2 + 1)];
+      tab[tab_index(d, x, y, z, bricked)] = s[((lc2 + 1) * kOctLds + (lb2 + 1)) * kOctLds + (la2 + 1)];
     }
   }
 }
@@ -258,10 +275,20 @@ hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz)
 }
 
 // d_dist9: table 0 = dist8 (written here from the octants), tables 1..8 = the directional ones
-hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
-                         uint8_t* d_dist9) {
-  const Dim d{rx, ry, rz};
+long long bricked_bytes(int rx, int ry, int rz) {
+  return (long long)((rx + 7) >> 3) * ((ry + 3) >> 2) * ((rz + 3) >> 2) * 128;
+}
+hipError_t launch_unbrick(hipStream_t st, const uint8_t* d_bricked, int rx, int ry, int rz, uint8_t* d_linear) {
   const long long total = (long long)rx * ry * rz;
+  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  unbrick_kernel<<<blocks, 256, 0, st>>>(d_bricked, Dim{rx, ry, rz}, d_linear);
+  return hipGetLastError();
+}
+
+hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
+                         uint8_t* d_dist9, bool bricked) {
+  const Dim d{rx, ry, rz};
+  const long long total = bricked ? bricked_bytes(rx, ry, rz) : (long long)rx * ry * rz;  // bytes per table
   uint8_t* oct = d_dist9 + total;
   const int na = (rx + kOctTile - 1) / kOctTile, nb = (ry + kOctTile - 1) / kOctTile,
             nc = (rz + kOctTile - 1) / kOctTile;
@@ -270,7 +297,7 @@ hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, i
     const int a_lo = max(0, k - (nb - 1) - (nc - 1)), a_hi = min(na - 1, k);
     if (a_hi < a_lo) continue;
     const dim3 grid((unsigned)((a_hi - a_lo + 1) * nb), 8u);
-    oct_tile_kernel<<<grid, 256, 0, st>>>(d_vox, d, iso, oct, k, a_lo, nb, nc);
+    oct_tile_kernel<<<grid, 256, 0, st>>>(d_vox, d, iso, oct, k, a_lo, nb, nc, total, bricked ? 1 : 0);
   }
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
   dist_from_oct_kernel<<<blocks, 256, 0, st>>>(oct, total, d_dist9);

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -72,6 +73,7 @@ struct Volume {
   int rx = 0, ry = 0, rz = 0;
   int accel_iso = -1;              // isoVal the tables were built for, -1 = stale
   unsigned long long oct_stride = 0;
+  bool bricked = false;            // dist8 / oct8 stored in 8x4x4-cell bricks (volumes beyond the caches)
   unsigned long long generation = 0;  // bumped whenever the bytes (may) have changed
   double accel_build_ms = 0.0;     // wall time of the last table build (reported by bench.py)
   ~Volume() {
@@ -97,13 +99,14 @@ struct rm_ctx {
                              // 16 + 9 measured 12 % faster than as 6 x 4 + 1)
   int waves_per_simd = 7;    // RAYMARCH_WAVES_PER_SIMD (4..8): register budget of the frame kernel
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
+  int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   // records validated by rm_check_device_opts
   std::vector<RmOpts> dev_recs;
   std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
   const void* dev_src = nullptr;
   int dev_iter = 0, dev_n = 0, dev_width = 0;
   unsigned long long dev_generation = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
   bool timed = false;
   int launches = 0;
   // rm_create_multi: the other devices of a multi-device context (this one is rank 0)
@@ -163,10 +166,14 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     // 8 % fill); table offsets are 64-bit, nine 1024^3 tables span 9 GiB
     const bool oct = c->use_octants;
     const int tables = oct ? 9 : 1;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    HIP_TRY(hipEventCreate(&t0));
-    HIP_TRY(hipEventCreate(&t1));
-    HIP_TRY(v.dist_buf.reserve(vox * tables));
+    // Row-major tables have the cheapest index arithmetic and win while the Infinity Cache
+    // catches most misses (bricks: +3 % at 256^3, equal at 512^3); far beyond it every miss
+    // goes to HBM and locality wins (1024^3: -6.6 %)
+    const bool bricked = oct && RM_COARSE == 0 &&
+                         (c->bricks >= 0 ? c->bricks == 1 : vox * 13 > ((size_t)4 << 30));
+    const size_t tbytes = bricked ? (size_t)rmk::bricked_bytes(v.rx, v.ry, v.rz) : vox;
+    hipEvent_t t0 = c->ev_b0, t1 = c->ev_b1;
+    HIP_TRY(v.dist_buf.reserve(tbytes * tables));
     uint8_t* lin = static_cast<uint8_t*>(v.dist_buf.p);
     HIP_TRY(v.surf_buf.reserve(vox * 4));
     HIP_TRY(hipEventRecord(t0, c->stream));
@@ -174,9 +181,11 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     if (oct) {
       HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, nullptr, nullptr,
                                static_cast<uint32_t*>(v.surf_buf.p)));
-      HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin));
-      v.oct_stride = vox;
+      HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin, bricked));
+      v.oct_stride = tbytes;
+      v.bricked = bricked;
     } else {
+      v.bricked = false;
       HIP_TRY(v.tmp_buf.reserve(vox));
       HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
                                static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
@@ -192,11 +201,10 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, t0, t1);
     v.accel_build_ms = ms;
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     v.accel_iso = iso;
   }
   out->oct_stride = v.oct_stride;
+  out->bricked = v.bricked;
   out->dist = static_cast<const uint8_t*>(v.dist_buf.p);
   out->surf = static_cast<const uint32_t*>(v.surf_buf.p);
 #if RM_COARSE
@@ -317,8 +325,8 @@ int new_volume(rm_ctx* c) {
   Volume* v = new (std::nothrow) Volume();
   if (!v) return fail(RM_EDEVICE, "out of host memory");
   v->device = c->device;
-  static unsigned long long next_generation = 1;
-  v->generation = next_generation++;
+  static std::atomic<unsigned long long> next_generation{1};
+  v->generation = next_generation.fetch_add(1);
   c->vol.reset(v);
   return RM_OK;
 }
@@ -367,6 +375,8 @@ static int create_one(int device_id, rm_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_b0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_b1);
   if (e != hipSuccess) {
     rm_destroy(c);
     return fail(RM_EDEVICE, "stream/event creation: %s", hipGetErrorString(e));
@@ -385,6 +395,8 @@ static int create_one(int device_id, rm_ctx** out) {
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) c->pass_pack = atoi(pk);
+  const char* bk = getenv("RAYMARCH_BRICKS");
+  if (bk && (bk[0] == '0' || bk[0] == '1')) c->bricks = bk[0] - '0';
   const char* pw = getenv("RAYMARCH_PACK_WASTE");
   if (pw && atoi(pw) >= 0 && atoi(pw) <= 100) c->pack_waste = atoi(pw);
   const char* sw = getenv("RAYMARCH_WAVES_PER_SIMD");
@@ -452,6 +464,8 @@ void rm_destroy(rm_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
+  if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -967,7 +981,13 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
   if (rc) return rc;
   if (!accel.dist) return fail(RM_ESTATE, "derived tables are not built for this volume size");
   const size_t vox = (size_t)c->vol->rx * c->vol->ry * c->vol->rz;
-  if (dist_out) HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
+  if (dist_out && accel.bricked) {  // what the kernels read, converted back to row-major
+    HIP_TRY(c->vol->tmp_buf.reserve(vox));
+    HIP_TRY(rmk::launch_unbrick(c->stream, accel.dist, c->vol->rx, c->vol->ry, c->vol->rz,
+                                static_cast<uint8_t*>(c->vol->tmp_buf.p)));
+    HIP_TRY(hipMemcpyAsync(dist_out, c->vol->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
+  } else if (dist_out)
+    HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
   if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
@@ -984,7 +1004,17 @@ int rm_debug_get_octants(rm_ctx* c, int iso, uint8_t* oct_out) {
   if (!accel.dist || !accel.oct_stride)
     return fail(RM_ESTATE, "directional tables are not built (disabled, or volume too large)");
   const size_t vox = (size_t)c->vol->rx * c->vol->ry * c->vol->rz;
-  HIP_TRY(hipMemcpyAsync(oct_out, accel.dist + vox, vox * 8, hipMemcpyDeviceToHost, c->stream));
+  if (accel.bricked) {
+    HIP_TRY(c->vol->tmp_buf.reserve(vox));
+    for (int t = 0; t < 8; t++) {
+      HIP_TRY(rmk::launch_unbrick(c->stream, accel.dist + (size_t)(t + 1) * accel.oct_stride, c->vol->rx,
+                                  c->vol->ry, c->vol->rz, static_cast<uint8_t*>(c->vol->tmp_buf.p)));
+      HIP_TRY(hipMemcpyAsync(oct_out + (size_t)t * vox, c->vol->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+  } else {
+    HIP_TRY(hipMemcpyAsync(oct_out, accel.dist + vox, vox * 8, hipMemcpyDeviceToHost, c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }

@@ -22,7 +22,12 @@ struct Accel {  // nullptrs = not available: the kernels then run the plain fixe
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
   unsigned long long oct_stride = 0;
   const uint8_t* coarse = nullptr;  // RM_COARSE: block minima of the 1 or 9 tables, table-major
+  bool bricked = false;             // dist / oct tables in 8x4x4-cell bricks of 128 B (oct_stride = bricked table bytes)
 };
+// bytes of one byte table in the bricked layout
+long long bricked_bytes(int rx, int ry, int rz);
+// bricked table -> row-major (test hooks)
+hipError_t launch_unbrick(hipStream_t st, const uint8_t* d_bricked, int rx, int ry, int rz, uint8_t* d_linear);
 long long coarse_bytes(int rx, int ry, int rz, int ntab);
 hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, int rz, int ntab, uint8_t* d_coarse);
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
@@ -60,7 +65,7 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
 // the 8 directional tables (d_dist9 = 9 * volume bytes: tables 1..8) and dist8 derived from
 // them (table 0); no scratch
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
-                         uint8_t* d_dist9);
+                         uint8_t* d_dist9, bool bricked = false);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // rm_volgen.hip: the other volume producers of the reference, on the device
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);

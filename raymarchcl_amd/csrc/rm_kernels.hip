@@ -63,13 +63,13 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
 // contiguous 1 KiB store per wave) instead of at the work-item id; used by the
 // device-resident pipeline and the multi-GPU partition, un-permuted by
 // resolve_kernel.
-template <bool COUNT, bool TILE_MAJOR, bool ACCEL>
+template <bool COUNT, bool TILE_MAJOR, bool ACCEL, bool BRICK = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
     const RmOpts* __restrict__ opts,
     float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
-    rmk::Counters* __restrict__ counters) {
+    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0) {
   const int resx = opts->resolution[0];
   const TileGeom g = tile_geom(resx, n);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   const long long tile = tile_first + slot * tile_stride;
   if (tile >= g.tiles_total) return;
   const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
-  rmk::Scene sc{vox, mc, opts, dist8, surf32};
-  rmk::Tracer<COUNT, ACCEL> tr(sc);
+  rmk::Scene sc{vox, mc, opts, dist8, surf32, oct_stride};
+  rmk::Tracer<COUNT, ACCEL, false, BRICK> tr(sc);
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
     const float fb = opts->frameBlend;
@@ -149,9 +149,9 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 #ifndef RM_PERSISTENT
 #define RM_PERSISTENT 0  // A/B: a resident grid whose wavefronts stride over the frame's blocks
 #endif
-template <bool ACCEL, bool SDFM, bool MULTI>
+template <bool ACCEL, bool SDFM, bool MULTI, bool BRICK>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
-  using Tr = rmk::Tracer<false, ACCEL, SDFM>;
+  using Tr = rmk::Tracer<false, ACCEL, SDFM, BRICK>;
   const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
@@ -266,18 +266,18 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
 #endif
 }
 
-template <bool ACCEL, int MINW, bool SDFM, bool MULTI>
+template <bool ACCEL, int MINW, bool SDFM, bool MULTI, bool BRICK = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
   __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
 #if RM_PERSISTENT
   // (stride = grid size, a multiple of 8: a wavefront stays on the tile rows of its XCD)
   for (long long b = blockIdx.x; b < a.total_blocks; b += gridDim.x) {
-    frame_block<ACCEL, SDFM, MULTI>(a, b, wave_lds);
+    frame_block<ACCEL, SDFM, MULTI, BRICK>(a, b, wave_lds);
     __syncthreads();
   }
 #else
-  frame_block<ACCEL, SDFM, MULTI>(a, blockIdx.x, wave_lds);
+  frame_block<ACCEL, SDFM, MULTI, BRICK>(a, blockIdx.x, wave_lds);
 #endif
 }
 
@@ -415,15 +415,16 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   float4* px4 = reinterpret_cast<float4*>(pixels);
   const dim3 grid(blocks), block(64 * kWavesPerBlock);
   const bool acc = accel.dist && accel.surf;
-#define RM_LAUNCH(C, T, A)                                                                      \
-  render_pass_kernel<C, T, A><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, \
-                                                      px4, n, id0, id1, tile_first, tile_stride, \
-                                                      d_counters)
-  if (d_counters) RM_LAUNCH(true, false, false);
-  else if (tile_major && acc) RM_LAUNCH(false, true, true);
-  else if (tile_major) RM_LAUNCH(false, true, false);
-  else if (acc) RM_LAUNCH(false, false, true);
-  else RM_LAUNCH(false, false, false);
+#define RM_LAUNCH(C, T, A, B)                                                                      \
+  render_pass_kernel<C, T, A, B><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, \
+                                                         px4, n, id0, id1, tile_first, tile_stride, \
+                                                         d_counters, accel.oct_stride)
+  if (d_counters) RM_LAUNCH(true, false, false, false);
+  else if (acc && accel.bricked) { if (tile_major) RM_LAUNCH(false, true, true, true); else RM_LAUNCH(false, false, true, true); }
+  else if (tile_major && acc) RM_LAUNCH(false, true, true, false);
+  else if (tile_major) RM_LAUNCH(false, true, false, false);
+  else if (acc) RM_LAUNCH(false, false, true, false);
+  else RM_LAUNCH(false, false, false, false);
 #undef RM_LAUNCH
   return hipGetLastError();
 }
@@ -485,23 +486,26 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
 #endif
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   const bool multi = f.passes > (1 << pp_log2);
-#define RM_FRAME(A, W, S)                                                    \
-  do {                                                                       \
-    if (multi) render_frame_kernel<A, W, S, true><<<grid, block, 0, st>>>(a); \
-    else render_frame_kernel<A, W, S, false><<<grid, block, 0, st>>>(a);      \
+#define RM_FRAME(A, W, S, B)                                                     \
+  do {                                                                           \
+    if (multi) render_frame_kernel<A, W, S, true, B><<<grid, block, 0, st>>>(a);  \
+    else render_frame_kernel<A, W, S, false, B><<<grid, block, 0, st>>>(a);       \
   } while (0)
   if (f.sdf) {
-    RM_FRAME(false, 4, true);
+    RM_FRAME(false, 4, true, false);
+  } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
+    // (volumes whose tables exceed the caches: one register budget, the default)
+    RM_FRAME(true, 7, false, true);
   } else if (f.accel.dist && f.accel.surf) {
     switch (f.min_waves) {
-      case 4: RM_FRAME(true, 4, false); break;
-      case 5: RM_FRAME(true, 5, false); break;
-      case 6: RM_FRAME(true, 6, false); break;
-      case 8: RM_FRAME(true, 8, false); break;
-      default: RM_FRAME(true, 7, false); break;
+      case 4: RM_FRAME(true, 4, false, false); break;
+      case 5: RM_FRAME(true, 5, false, false); break;
+      case 6: RM_FRAME(true, 6, false, false); break;
+      case 8: RM_FRAME(true, 8, false, false); break;
+      default: RM_FRAME(true, 7, false, false); break;
     }
   } else {
-    RM_FRAME(false, 3, false);
+    RM_FRAME(false, 3, false, false);
   }
 #undef RM_FRAME
   return hipGetLastError();

@@ -148,6 +148,11 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // most floor(k*s + eps) + 1; samples 1 .. j-1 are therefore certainly empty for
 // j = 1 + floor(0.98 * (d-1) / s)   (inv_s = 0.98 / s; the 2 % absorb the <= 0.01
 // cell of accumulated rounding drift and the rounding of p*res).
+// BRICK: the tables are stored in 8x4x4-cell bricks of 128 bytes = one cache line each
+// (rm_accel.hip), chosen by the host for volumes whose tables exceed the Infinity Cache: a ray's
+// consecutive fetches and the lanes of a wavefront then share lines instead of touching a new
+// 128-byte row segment per fetch.
+template <bool BRICK = false>
 RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
                      float inv_s, int* cell_out, unsigned long long table_off = 0, unsigned int* dhist = nullptr,
                      const uint8_t* __restrict__ coarse = nullptr, unsigned int coarse_off = 0) {
@@ -157,23 +162,37 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
   // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
   // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
-  const unsigned cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
-                                 (unsigned)o.voxelRes[0]) + (unsigned)qx;
+  unsigned cell;
+  int d;
+  if (BRICK) {
+    const unsigned nbx = ((unsigned)o.voxelRes[0] + 7u) >> 3, nby = ((unsigned)o.voxelRes[1] + 3u) >> 2;
+    const unsigned brick = __umul24(__umul24((unsigned)qz >> 2, nby) + ((unsigned)qy >> 2), nbx) + ((unsigned)qx >> 3);
+    const unsigned within = ((((unsigned)qz & 3u) << 2 | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
+    cell = 0;
+    // (64-bit: the bricks of a 1024^3 table alone are 1 GiB; 9 tables follow each other)
+    d = dist8[(((unsigned long long)brick << 7) | within) + table_off];
+  } else {
+    cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
+                    (unsigned)o.voxelRes[0]) + (unsigned)qx;
 #if RM_COARSE
-  // block minimum first (a lower bound of the cell's value: a shorter but valid skip); the
-  // fine table only where the bound is too small to be useful
-  const unsigned bx = ((unsigned)o.voxelRes[0] + 3u) >> 2, by = ((unsigned)o.voxelRes[1] + 3u) >> 2;
-  const unsigned blk = __umul24(__umul24((unsigned)qz >> 2, by) + ((unsigned)qy >> 2), bx) + ((unsigned)qx >> 2);
-  int d = coarse[coarse_off + blk];
-  if (d < RM_COARSE_MIN) d = dist8[cell + table_off];
+    // block minimum first (a lower bound of the cell's value: a shorter but valid skip); the
+    // fine table only where the bound is too small to be useful
+    const unsigned bx = ((unsigned)o.voxelRes[0] + 3u) >> 2, by = ((unsigned)o.voxelRes[1] + 3u) >> 2;
+    const unsigned blk = __umul24(__umul24((unsigned)qz >> 2, by) + ((unsigned)qy >> 2), bx) + ((unsigned)qx >> 2);
+    d = coarse[coarse_off + blk];
+    if (d < RM_COARSE_MIN) d = dist8[cell + table_off];
 #else
-  const int d = dist8[cell + table_off];
+    d = dist8[cell + table_off];
 #endif
+  }
   if (dhist) {  // stats build only
     dhist[d < 4 ? d : (d < 8 ? 4 : 5)]++;
     dhist[6] = (unsigned)d;
   }
   if (d == 0) {
+    if (BRICK)  // surf32 stays row-major
+      cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy, (unsigned)o.voxelRes[0]) +
+             (unsigned)qx;
     *cell_out = (int)cell;
     return 1;
   }
@@ -220,7 +239,7 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 #endif
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
 // come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
-template <bool COUNT, bool ACCEL = false, bool SDFM = false>
+template <bool COUNT, bool ACCEL = false, bool SDFM = false, bool BRICK = false>
 struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
   static_assert(!(SDFM && (COUNT || ACCEL)), "the quality mode has no counters and no derived tables");
@@ -521,9 +540,9 @@ struct Tracer {
           RM_WS(ws_steps += (unsigned)steps);
           RM_WS(ws_nf++);
 #ifdef RM_WORK_STATS
-          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist, sc.coarse, coarse_off);
+          r = walk_step<BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist, sc.coarse, coarse_off);
 #else
-          r = walk_step(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, nullptr, sc.coarse, coarse_off);
+          r = walk_step<BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, nullptr, sc.coarse, coarse_off);
 #endif
           RM_WS(ws_steps -= (unsigned)steps);
 #ifdef RM_WORK_STATS

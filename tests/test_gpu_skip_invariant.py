@@ -1,0 +1,88 @@
+"""The claim the accelerated walk rests on, checked directly (not through pixels): whenever the
+kernel's walk_step fetches the table value d at a sample and advances j = 1 + floor(0.98 (d-1) / s)
+samples at once (rm_shade.hpp), the j-1 samples it does not look at lie in empty cells inside the
+grid -- so the reference, which fetches every sample, would neither hit nor stop there.
+
+The tables come from the device (dist8 and the eight directional tables of the resident volume);
+the walk is replayed on the host in float32 with the reference's sequential position adds, for
+random rays, step counts and ANISOTROPIC step vectors, at 128^3 and 256^3.  j is taken a rounding
+step LARGER than the device's (its reciprocal is a 1-ulp approximation), so the check covers
+whatever the hardware computes."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.mark.parametrize("kind,res,iso,rays", [("gyroid", 256, 32, 30000), ("terrain", 128, 32, 20000),
+                                              ("gyroid", 128, 100, 20000), ("sparse-blobs", 64, 32, 20000)])
+def test_skipped_samples_are_empty_and_in_grid(gpu_ctx, kind, res, iso, rays):
+    if kind == "sparse-blobs":
+        from raymarchcl_amd import generators as gen
+
+        vox = gen.make_blob_volume(res, radius=(0.01, 0.03))
+    else:
+        vox = scenes.volume(kind, res)
+    gpu_ctx.set_volume(vox, (res,) * 3)
+    dist, _ = gpu_ctx.debug_get_accel(iso)
+    octs = gpu_ctx.debug_get_octants(iso).reshape(8, -1)
+    tables = np.concatenate([dist[None, :], octs])  # table 0 = dist8, 1 + octant = directional
+    hit = vox > iso
+    rng = np.random.default_rng(res + iso)
+    n = rays
+    # starts anywhere in (and slightly outside) the unit cube, directions anywhere, per-axis scale
+    p = rng.uniform(-0.02, 1.02, (n, 3)).astype(F)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    steps = rng.choice([96, 192, 33, 400], n).astype(np.int32)
+    scale = rng.choice([1.0, 0.8, 1.25], (n, 3))
+    delta = (d * scale / (steps[:, None] * 0.5) * 0.5).astype(F)  # dir / sf * invVoxelScale
+    fres = F(res)
+    s = np.max(np.abs(delta) * fres, axis=1).astype(F)
+    inv_s = (F(0.98) / np.maximum(s, F(1e-6))).astype(F) * F(1 + 2.0 ** -21)  # >= the device's
+    use_oct = rng.random(n) < 0.8
+    octant = ((delta[:, 0] < 0) * 1 + (delta[:, 1] < 0) * 2 + (delta[:, 2] < 0) * 4).astype(np.int64)
+    table = np.where(use_oct, 1 + octant, 0)
+    alive = np.ones(n, bool)
+    fetches = skipped = 0
+    for _ in range(400):
+        if not alive.any():
+            break
+        q = (p * fres).astype(np.int32)  # trunc toward zero (values are far from the int32 range)
+        ingrid = ((q >= 0) & (q < res)).all(axis=1)
+        alive &= ingrid & (steps > 0)
+        idx = np.where(alive)[0]
+        if idx.size == 0:
+            break
+        cell = (q[idx, 2].astype(np.int64) * res + q[idx, 1]) * res + q[idx, 0]
+        dv = tables[table[idx], cell].astype(np.int32)
+        assert (hit[cell] == (dv == 0)).all()  # 0 marks exactly the cells the march would hit
+        ended = dv == 0
+        alive[idx[ended]] = False
+        idx, dv = idx[~ended], dv[~ended]
+        roomy = p[idx].min(axis=1) >= F(0.015625)
+        j = np.where(roomy, 1 + ((dv - 1).astype(F) * inv_s[idx]).astype(np.int32), 1)
+        done = j >= steps[idx]
+        alive[idx[done]] = False
+        idx, j = idx[~done], j[~done]
+        fetches += idx.size
+        # walk the j samples one add at a time; samples 1 .. j-1 must be empty and in the grid
+        left = j.copy()
+        cur = idx
+        while cur.size:
+            p[cur] = (p[cur] + delta[cur]).astype(F)
+            left = left - 1
+            chk = left > 0
+            c2 = cur[chk]
+            if c2.size:
+                qq = (p[c2] * fres).astype(np.int32)
+                assert ((qq >= 0) & (qq < res)).all(), "a skipped sample leaves the grid"
+                cc = (qq[:, 2].astype(np.int64) * res + qq[:, 1]) * res + qq[:, 0]
+                assert not hit[cc].any(), "a skipped sample lies in a cell the march would hit"
+                skipped += c2.size
+            cur, left = cur[chk], left[chk]
+        steps[idx] -= j
+    assert fetches > n and skipped > fetches // 4  # the check saw real skips
