@@ -106,7 +106,7 @@ struct rm_ctx {
   const void* dev_src = nullptr;
   int dev_iter = 0, dev_n = 0, dev_width = 0;
   unsigned long long dev_generation = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_in = nullptr;
   bool timed = false;
   int launches = 0;
   // rm_create_multi: the other devices of a multi-device context (this one is rank 0)
@@ -375,6 +375,7 @@ static int create_one(int device_id, rm_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b1);
   if (e != hipSuccess) {
@@ -464,6 +465,7 @@ void rm_destroy(rm_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
   if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -739,11 +741,25 @@ static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), world);
   const size_t part_bytes = (size_t)tpp * 64 * 16;
   HIP_TRY(c->tile_buf.reserve(part_bytes * world));
+  // the records and tables cross PCIe once, to the root; the other devices take them from
+  // there over xGMI (asynchronous: the host gets all n launches out without waiting for n uploads)
+  {
+    int rc = upload_frame_inputs(c, opts_array, mc_array, iter);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev_in, c->stream));
+  }
+  const size_t opts_bytes = (size_t)iter * RM_OPTS_BYTES, mc_bytes = (size_t)iter * RM_TABLE_FLOATS * 4;
   for (int r = 0; r < world; r++) {
     rm_ctx* d = r == 0 ? c : c->peers[r - 1];
     HIP_TRY(hipSetDevice(d->device));
-    int rc = upload_frame_inputs(d, opts_array, mc_array, iter);
-    if (rc) return rc;
+    if (r > 0) {
+      HIP_TRY(d->opts_buf.reserve(opts_bytes));
+      HIP_TRY(d->mc_buf.reserve(mc_bytes));
+      HIP_TRY(hipStreamWaitEvent(d->stream, c->ev_in, 0));
+      HIP_TRY(hipMemcpyPeerAsync(d->opts_buf.p, d->device, c->opts_buf.p, c->device, opts_bytes, d->stream));
+      HIP_TRY(hipMemcpyPeerAsync(d->mc_buf.p, d->device, c->mc_buf.p, c->device, mc_bytes, d->stream));
+    }
+    int rc = RM_OK;
     FrameOut out;
     if (r > 0) HIP_TRY(d->tile_buf.reserve(part_bytes));
     out.acc = static_cast<float*>(r == 0 ? c->tile_buf.p : d->tile_buf.p);
