@@ -261,6 +261,14 @@ int rm_vox_load(const char* path, uint8_t* out, size_t capacity);
  *     6 (uint)a [x86], 7 convert_int_sat(a), 8 a*b+c unfused (c = a).
  * a, b: n floats (b may be NULL for unary ops); out: n 32-bit words. */
 int rm_selftest_prims(rm_ctx* ctx, int op, const float* a, const float* b, uint32_t* out, int n);
+/* The exact-outcome shortcuts of the march next to the exact slab test (renderer.cl:153-161,
+ * :214) they stand in for.  rays: n x 8 floats (origin xyz, direction xyz, march distance t,
+ * ground term g); out[i] bits: 1 the filter says "this estimate certainly does not walk",
+ * 2 "the position is certainly inside the clip box (the slab test returns exactly +0 < g)",
+ * 4 the exact test says the estimate walks (0 <= t_in < g), 8 the exact slab test returned
+ * exactly +0, 16 the position passes the inside-by-a-margin shortcut of the estimate.
+ * A correct library never reports 1 with 4, nor 2 or 16 without 8. */
+int rm_selftest_filter(rm_ctx* ctx, const void* opts544, const float* rays, int n, uint32_t* out);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ EXPORTS = [
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims", "rm_selftest_filter",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
@@ -138,6 +138,7 @@ def lib():
     L.rm_check_device_opts.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
     L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
+    L.rm_selftest_filter.argtypes = [_vp, _vp, _vp, _i, _vp]
     L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
     L.rm_debug_get_octants.argtypes = [_vp, _i, _vp]
     _lib = L
@@ -368,6 +369,14 @@ class Context:
         out = np.zeros(8 * rx * ry * rz, dtype=np.uint8)
         check(lib().rm_debug_get_octants(self._h, iso, out.ctypes.data))
         return out.reshape(8, rz, ry, rx)
+
+    def selftest_filter(self, opts, rays):
+        """rays: float32 [n, 8] (origin, direction, t, g) -> uint32 [n] of decision bits (header)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], dtype=np.uint32)
+        check(lib().rm_selftest_filter(self._h, self._opts(bytes(opts)[:OPTS_BYTES]), rays.ctypes.data,
+                                       rays.shape[0], out.ctypes.data))
+        return out
 
     def selftest_prims(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)

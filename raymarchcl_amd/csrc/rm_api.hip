@@ -1035,6 +1035,23 @@ int rm_debug_get_octants(rm_ctx* c, int iso, uint8_t* oct_out) {
   return RM_OK;
 }
 
+int rm_selftest_filter(rm_ctx* c, const void* opts544, const float* rays, int n, uint32_t* out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!opts544 || !rays || !out || n < 0) return fail(RM_EINVAL, "bad argument");
+  if (n == 0) return RM_OK;
+  HIP_TRY(c->opts_buf.reserve(RM_OPTS_BYTES));
+  HIP_TRY(c->prim_a.reserve((size_t)n * 32));
+  HIP_TRY(c->prim_o.reserve((size_t)n * 4));
+  HIP_TRY(hipMemcpyAsync(c->opts_buf.p, opts544, RM_OPTS_BYTES, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->prim_a.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(rmk::launch_filter_check(c->stream, static_cast<const float*>(c->prim_a.p),
+                                   static_cast<const RmOpts*>(c->opts_buf.p), static_cast<uint32_t*>(c->prim_o.p), n));
+  HIP_TRY(hipMemcpyAsync(out, c->prim_o.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
 int rm_selftest_prims(rm_ctx* c, int op, const float* a, const float* b, uint32_t* out, int n) {
   int rc = check_ctx(c);
   if (rc) return rc;

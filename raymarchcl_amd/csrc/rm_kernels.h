@@ -72,6 +72,7 @@ hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz
 hipError_t launch_splat(hipStream_t st, uint8_t* d_out, const double* d_xyz, long long n,
                         const double p[3], const double off[3], double s, int res, int ks);
 hipError_t launch_heatmap(hipStream_t st, uint8_t* d_out, const uint32_t* d_argb, int res, double amp);
+hipError_t launch_filter_check(hipStream_t st, const float* d_rays, const RmOpts* d_opts, uint32_t* d_out, int n);
 hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,
                         int n);
 }  // namespace rmk

@@ -338,9 +338,43 @@ __global__ void prims_kernel(int op, const float* __restrict__ a, const float* _
   out[i] = r;
 }
 
+// Device side of rm_selftest_filter: the decisions of the slab-test filter and of the
+// inside-the-box shortcut next to the exact slab test they stand in for.
+__global__ void filter_check_kernel(const float* __restrict__ rays, const RmOpts* __restrict__ opts,
+                                    uint32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rays + (size_t)i * 8;
+  const rmk::v3 ro = rmk::V(r[0], r[1], r[2]), rd = rmk::V(r[3], r[4], r[5]);
+  const float t = r[6], g = r[7];
+  rmk::Scene sc{nullptr, nullptr, opts, nullptr, nullptr};
+  rmk::Tracer<false, true> tr(sc);
+  const auto flt = tr.make_filter(ro, rd);
+  const rmk::v3 rpos = rmk::mads(rd, t, ro);  // the position march() hands to the estimate
+  const float t_in = rmk::box_entry_of(*opts, rpos, rd);
+  const RmOpts& o = *opts;
+  const float m = 1e-4f;  // scene_distance's RM_INSIDE_TEST margin
+  const bool inside = (rpos.x - o.voxelBoundsMin[0] > m) & (o.voxelBoundsMax[0] - rpos.x > m) &
+                      (rpos.y - o.voxelBoundsMin[1] > m) & (o.voxelBoundsMax[1] - rpos.y > m) &
+                      (rpos.z - o.voxelBoundsMin[2] > m) & (o.voxelBoundsMax[2] - rpos.z > m);
+  uint32_t bits = 0;
+  if (tr.surely_no_walk(flt, t, g)) bits |= 1u;
+  if (tr.surely_inside(flt, t, g)) bits |= 2u;
+  if (t_in >= 0.0f && t_in < g) bits |= 4u;                    // renderer.cl:214: the estimate walks
+  if (__float_as_uint(t_in) == 0u) bits |= 8u;                 // the slab test returned exactly +0
+  if (inside) bits |= 16u;
+  out[i] = bits;
+}
+
 }  // namespace
 
 namespace rmk {
+
+hipError_t launch_filter_check(hipStream_t st, const float* rays, const RmOpts* d_opts, uint32_t* out, int n) {
+  if (n <= 0) return hipSuccess;
+  filter_check_kernel<<<(n + 255) / 256, 256, 0, st>>>(rays, d_opts, out, n);
+  return hipGetLastError();
+}
 
 int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
