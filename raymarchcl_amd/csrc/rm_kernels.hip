@@ -241,7 +241,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
       for (int k = 0; k < 4; k++) ws_acc[44 + k] += tr.ws_k_nohit[k];
       ws_acc[38] += tr.ws_k_one[0] + tr.ws_k_one[1];
       ws_acc[39] += tr.ws_k_one[2];
-      ws_acc[40] += tr.ws_pairs; ws_acc[41] += tr.ws_pairs_back; ws_acc[42] += tr.ws_pairs_dark;
+      ws_acc[40] += tr.ws_pairs; ws_acc[41] += tr.ws_pairs_back; ws_acc[42] += tr.ws_pairs_dark; ws_acc[51] += tr.ws_pairs_skipped;
       ws_acc[0] += 1;
     }
     {
@@ -405,8 +405,10 @@ void dump_work_stats() {
                   "(%.1f of them after the walk's last fetch with value <= 1)\n",
           h[29] / n, h[30] / n, h[31] / n);
   fprintf(stderr, "[work stats] (hit, light) pairs per sample %.2f: %.1f%% face away from the light, %.1f%% of all have "
-                  "no specular term either; last turn repeated for its normal in %.3f marches per sample\n",
-          h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1), h[43] / n);
+                  "no specular term either (%.1f%% of all: shadow march not traced); last turn repeated for its normal in %.3f "
+                  "marches per sample\n",
+          h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1),
+          100.0 * h[51] / (h[40] ? h[40] : 1), h[43] / n);
   fprintf(stderr, "[work stats] walks without a hit per sample: primary %.2f, reflection %.2f, shadow %.2f, AO %.2f; "
                   "ended by their first fetch: primary+reflection %.2f, shadow %.2f\n",
           h[44] / n, h[45] / n, h[46] / n, h[47] / n, h[38] / n, h[39] / n);

@@ -235,6 +235,9 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 #define RM_LAZY_NORMAL 1  // primary / reflection marches: walks reach as far as the ground term; last turn repeated if cut
 #endif
 #ifndef RM_INSIDE_TEST
+#ifndef RM_DARK_SKIP
+#define RM_DARK_SKIP 1    // shadow marches whose result is multiplied by exact zeros are not traced
+#endif
 #define RM_INSIDE_TEST 1  // skip the slab test when the position is inside the box by a margin
 #endif
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
@@ -266,6 +269,7 @@ struct Tracer {
   unsigned int ws_k_nohit[4] = {0, 0, 0, 0}, ws_k_one[4] = {0, 0, 0, 0};  // walks without a hit; of those, ended by their first fetch
   unsigned int ws_k_est[4] = {0, 0, 0, 0}, ws_k_filt[4] = {0, 0, 0, 0};  // estimate / filtered turns by march kind
   unsigned int ws_redo = 0;  // marches whose last turn was repeated for its normal
+  unsigned int ws_pairs_skipped = 0;
   unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
   RM_DEV unsigned int wave_slots() {
@@ -971,6 +975,15 @@ struct Tracer {
   RM_DEV int& lds_map(int rank) { return reinterpret_cast<int*>(lds_)[(kWaveLdsIn + kWaveLdsRes) * 64 + rank]; }
   RM_DEV static void wave_sync() { __syncthreads(); }  // one wavefront per workgroup: orders its LDS traffic
 
+  // bit patterns +0 .. +inf (no sign bit, not NaN) / +0 .. largest finite
+  RM_DEV static bool sign_clear(v3 a) {
+    return (__float_as_uint(a.x) <= 0x7f800000u) & (__float_as_uint(a.y) <= 0x7f800000u) &
+           (__float_as_uint(a.z) <= 0x7f800000u);
+  }
+  RM_DEV static bool finite_nonneg(v3 a) {
+    return (__float_as_uint(a.x) < 0x7f800000u) & (__float_as_uint(a.y) < 0x7f800000u) &
+           (__float_as_uint(a.z) < 0x7f800000u);
+  }
   struct Deal {  // who does what in a shared phase
     int lane, helpers, my_slot, owners, my_rank;
   };
@@ -1064,6 +1077,39 @@ struct Tracer {
 
   // the shadow marches of lighting() for all lanes: distance reached by the march towards
   // light i in lds_res(i, lane) (only where the light passes the attenuation test)
+#if RM_DARK_SKIP
+  // `need`: bit i set = this lane owns a hit whose light i needs its shadow march (lighting_wave)
+  RM_DEV void shadows_wave(unsigned int need, v3 hitpos, v3 jit) {
+    const RmOpts& o = *sc.o;
+    const int nl = o.numLights;
+    const bool active = need != 0u;
+    const Deal dl = deal(active);
+    if (dl.owners == 0 || nl <= 0) return;
+    if (active) {
+      lds_in(0, dl.lane) = hitpos.x; lds_in(1, dl.lane) = hitpos.y; lds_in(2, dl.lane) = hitpos.z;
+      lds_in(3, dl.lane) = jit.x; lds_in(4, dl.lane) = jit.y; lds_in(5, dl.lane) = jit.z;
+    }
+    // the task list, light-major: one byte (light << 6 | owner lane) per needed (owner, light) pair
+    uint8_t* const task_of = reinterpret_cast<uint8_t*>(&lds_map(0));
+    int tasks = 0;
+    for (int i = 0; i < nl && i < 4; i++) {  // uniform
+      const bool mine = (need >> i) & 1u;
+      const unsigned long long mk = __ballot(mine);
+      if (mine) task_of[tasks + __popcll(mk & ((1ull << dl.lane) - 1ull))] = (uint8_t)((i << 6) | dl.lane);
+      tasks += __popcll(mk);
+    }
+    wave_sync();
+#ifdef RM_WORK_STATS
+    const int ws_kind_saved = ws_kind;
+    ws_kind = 2;
+#endif
+    for (int base = 0; base < tasks; base += dl.helpers) {
+      const int t = base + dl.my_slot;
+      if (t < tasks) {
+        RM_CLK_T(ck_s0);
+        const int e = task_of[t];
+        const int light = e >> 6, owner = e & 63;
+#else
   RM_DEV void shadows_wave(bool active, v3 hitpos, v3 jit) {
     const RmOpts& o = *sc.o;
     const int nl = o.numLights;
@@ -1087,6 +1133,7 @@ struct Tracer {
         RM_CLK_T(ck_s0);
         divmod_small(t, dl.owners, light, rank);
         const int owner = lds_map(rank);
+#endif
         const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
         const v3 ojit = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
         // the expressions of lighting() (renderer.cl:356-362)
@@ -1130,7 +1177,42 @@ struct Tracer {
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_c2 = ws_now();
 #endif
+#if RM_DARK_SKIP
+    // Which (hit, light) pairs need their shadow march at all.  A pair whose diffuse and
+    // specular factors are both exactly +0 (the light is behind the surface: max(0, l.n) = 0,
+    // and the half vector too, so blinn_phong takes its `return 0`) adds lightColor*sh*att * 0
+    // to the running sums (renderer.cl:368-372): +0 when that product is finite and not
+    // negative, and x + (+0) == x bit for bit for every x that is not -0.  The running sums
+    // start from sky*ao / reflectCol*ao and only ever see + (non-negative) and * albedo, so if
+    // all of those have a clear sign bit (and are not NaN) they never hold -0: the shadow
+    // term of such a pair cannot reach the result and its march -- about a quarter of all
+    // shadow marches -- is not traced.  (4 lights at most, the size of the record's arrays.)
+    unsigned int need = 0u;
+    if (active) {
+      const Material m = material(objectID);
+      const v3 rc = mirror_sky ? sky(reflect(raydir, normal)) : reflectCol;
+      const v3 d0 = sky(normal) * ao, s0 = rc * ao;
+      bool clean = sign_clear(d0) & sign_clear(s0) & sign_clear(m.albedo);
+      unsigned int dark = 0u;
+      for (int i = 0; i < o.numLights && i < 4; i++) {
+        const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
+        const float att = 1.0f / dot(dl, dl);
+        if (att > o.minLightAtt) {
+          need |= 1u << i;
+          const v3 ldir = normalize(dl);
+          const v3 inc = ld3(o.lightColor[i]) * att;
+          clean &= finite_nonneg(inc);
+          const bool back = rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f;
+          if (back && !(dot(normalize(ldir - raydir), normal) > 0.0f)) dark |= 1u << i;
+        }
+      }
+      if (clean) need &= ~dark;
+      RM_WS(ws_pairs_skipped += (unsigned)__builtin_popcount(clean ? dark : 0u));
+    }
+    shadows_wave(need, hitpos, jit);
+#else
     shadows_wave(active, hitpos, jit);
+#endif
 #ifdef RM_PHASE_CLOCK
     const unsigned long long ws_c3 = ws_now();
     if (ws_c2 && ws_c3) ws_clk[3] += ws_c3 - ws_c2;

@@ -50,12 +50,15 @@ def _rays(rng, lo, hi, count):
     near = np.nanmax(np.minimum(t0, t1), axis=1)
     far = np.nanmin(np.maximum(t0, t1), axis=1)
     t = rng.uniform(0.0, 12.0, count)
-    pick = rng.integers(0, 6, count)
-    ulps = rng.integers(-40, 41, count)
+    pick = rng.integers(0, 8, count)
+    ulps = rng.integers(-40, 41, count).astype(np.int32)
     for sel, base in ((pick == 1, near), (pick == 2, far)):
         b = np.where(np.isfinite(base), base, 1.0).astype(np.float32)
         moved = (b.view(np.int32) + ulps).view(np.float32)
         t = np.where(sel, moved, t)
+    # ... somewhere between entry and exit (inside the box): the "inside" shortcuts' territory
+    span = np.where(np.isfinite(near) & np.isfinite(far) & (far > near), far - near, 0.0)
+    t = np.where(pick >= 6, np.where(np.isfinite(near), near, 0.0) + span * rng.uniform(-0.02, 1.02, count), t)
     # ... and a little before the entry: the ground term then decides whether the estimate walks
     g_consistent = np.minimum((rd[:, 1] * t + ro[:, 1]) + 1.0, 1e5)
     gap = np.where(np.isfinite(near), near - t, 1.0)

@@ -77,6 +77,19 @@ def main():
                 over["startDist"] = float(rng.uniform(0.0, 1.5))
             if rng.random() < 0.3:
                 over["up"] = [float(v) for v in rng.normal(size=3)]
+        if rng.random() < 0.15:
+            # signs and zeros in the inputs the unlit-pair shortcut of lighting_wave reasons about
+            nl = int(rng.integers(1, 5))
+            over.update(numLights=nl, minLightAtt=float(rng.choice([0.0, 0.0, 0.05, 0.2])),
+                        lightPos=[[float(v) for v in rng.uniform(-2.5, 2.5, 3)] + [0.0] for _ in range(nl)],
+                        lightColor=[[float(v) for v in rng.choice([-30.0, -0.0, 0.0, 20.0, 60.0], 3)] + [0.0]
+                                    for _ in range(nl)])
+            if rng.random() < 0.5:
+                over["materials"] = [dict(albedo=[float(v) for v in rng.choice([-0.5, -0.0, 0.0, 0.3, 1.5], 3)] + [1.0],
+                                          r0=float(rng.choice([0.0, 0.1, 0.7])), smoothness=float(rng.uniform(0, 1)))
+                                     for _ in range(4)]
+            if rng.random() < 0.5:
+                over["skyColor1"] = [float(v) for v in rng.choice([-1.0, -0.0, 0.0, 1.8], 3)]
         recs = []
         for i in range(it):
             o = rm.render_options(t=i * 0.333, **base)
