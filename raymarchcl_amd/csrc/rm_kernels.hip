@@ -244,6 +244,8 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
       ws_acc[40] += tr.ws_pairs; ws_acc[41] += tr.ws_pairs_back; ws_acc[42] += tr.ws_pairs_dark; ws_acc[51] += tr.ws_pairs_skipped;
       ws_acc[0] += 1;
     }
+    ws_acc[55] += tr.ws_sh[0];
+    for (int k = 1; k < 6; k++) ws_acc[58 + k] += tr.ws_sh[k];  // (56..63 hold phase clocks in the other debug build)
     {
       const unsigned int v[32] = {0u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
                                   tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
@@ -409,6 +411,11 @@ void dump_work_stats() {
                   "marches per sample\n",
           h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1),
           100.0 * h[51] / (h[40] ? h[40] : 1), h[43] / n);
+  fprintf(stderr, "[work stats] shadow phases with tasks: %.0f, tasks per phase %.1f (%.1f%% without any estimate turn), "
+                  "rounds per phase %.2f (%.1f%% of the phases need more than one), rounds of marches WITH estimate turns if the "
+                  "others ran apart: %.2f\n",
+          (double)h[55], (double)h[61] / (h[55] ? h[55] : 1), 100.0 * h[62] / (h[61] ? h[61] : 1),
+          (double)h[59] / (h[55] ? h[55] : 1), 100.0 * h[63] / (h[55] ? h[55] : 1), (double)h[60] / (h[55] ? h[55] : 1));
   fprintf(stderr, "[work stats] walks without a hit per sample: primary %.2f, reflection %.2f, shadow %.2f, AO %.2f; "
                   "ended by their first fetch: primary+reflection %.2f, shadow %.2f\n",
           h[44] / n, h[45] / n, h[46] / n, h[47] / n, h[38] / n, h[39] / n);

@@ -270,6 +270,11 @@ struct Tracer {
   unsigned int ws_k_est[4] = {0, 0, 0, 0}, ws_k_filt[4] = {0, 0, 0, 0};  // estimate / filtered turns by march kind
   unsigned int ws_redo = 0;  // marches whose last turn was repeated for its normal
   unsigned int ws_pairs_skipped = 0;
+  // shadow phases: calls with tasks, rounds as run, rounds if marches without any estimate turn
+  // (the ray never comes near the clip box: filtered turns only) ran in rounds of their own,
+  // tasks, tasks of that cheap kind  [counted by one lane per wavefront]
+  unsigned int ws_sh[6] = {0, 0, 0, 0, 0, 0};
+  unsigned int ws_march_est = 0;  // estimate turns of the last march
   unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
   RM_DEV unsigned int wave_slots() {
@@ -676,6 +681,7 @@ struct Tracer {
     RM_WS(ws_rays++);
     RM_CLK_T(ck_m0);
     float dist = o.startDist;
+    RM_WS(ws_march_est = 0);
     // (the filter reasons about the clip box of the byte grid: off for the counting variant,
     //  which must run the plain algorithm, and for the quality mode, whose field extends
     //  beyond the box)
@@ -737,6 +743,7 @@ struct Tracer {
       float sd;
       RM_WS(wv_est += wave_slots());
       RM_WS(ws_k_est[ws_kind]++);
+      RM_WS(ws_march_est++);
       const bool inside = kFilter && surely_inside(flt, dist, g);
       int limit = 0x7fffffff;
       // (`dist` counts in units of |rdir|: the remaining world distance is (maxDist - dist) * |rdir|)
@@ -776,6 +783,7 @@ struct Tracer {
     }
     r.distance = dist;
   }
+
 
   RM_DEV v3 sky(v3 dir) { return sky_of(*sc.o, dir); }
 
@@ -1102,6 +1110,7 @@ struct Tracer {
 #ifdef RM_WORK_STATS
     const int ws_kind_saved = ws_kind;
     ws_kind = 2;
+    int ws_cheap_total = 0;
 #endif
     for (int base = 0; base < tasks; base += dl.helpers) {
       const int t = base + dl.my_slot;
@@ -1109,6 +1118,7 @@ struct Tracer {
         RM_CLK_T(ck_s0);
         const int e = task_of[t];
         const int light = e >> 6, owner = e & 63;
+        RM_WS(ws_march_est = 1);  // (a task that fails the attenuation test: cannot happen here)
 #else
   RM_DEV void shadows_wave(bool active, v3 hitpos, v3 jit) {
     const RmOpts& o = *sc.o;
@@ -1150,7 +1160,24 @@ struct Tracer {
           lds_res(light, owner) = h.distance;
         }
       }
+#ifdef RM_WORK_STATS
+      {
+        const int cheap = __popcll(__ballot(t < tasks && ws_march_est == 0));
+        if (dl.my_slot == 0) ws_sh[4] += (unsigned)cheap;
+        ws_cheap_total += cheap;
+      }
+#endif
     }
+#ifdef RM_WORK_STATS
+    if (dl.my_slot == 0 && tasks > 0) {
+      ws_sh[0] += 1u;
+      ws_sh[1] += (unsigned)((tasks + dl.helpers - 1) / dl.helpers);
+      const int costly = tasks - ws_cheap_total;
+      ws_sh[2] += (unsigned)((costly + dl.helpers - 1) / dl.helpers);
+      ws_sh[3] += (unsigned)tasks;
+      if (tasks > dl.helpers) ws_sh[5] += 1u;
+    }
+#endif
     RM_WS(ws_kind = ws_kind_saved);
     wave_sync();
   }
