@@ -244,6 +244,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
       ws_acc[40] += tr.ws_pairs; ws_acc[41] += tr.ws_pairs_back; ws_acc[42] += tr.ws_pairs_dark; ws_acc[51] += tr.ws_pairs_skipped;
       ws_acc[0] += 1;
     }
+    for (int k = 0; k < 3; k++) { ws_acc[32 + k] += tr.ws_k_follow[k]; ws_acc[35 + k] += tr.ws_k_follow_ground[k]; }
     ws_acc[55] += tr.ws_sh[0];
     for (int k = 1; k < 6; k++) ws_acc[58 + k] += tr.ws_sh[k];  // (56..63 hold phase clocks in the other debug build)
     {
@@ -411,6 +412,9 @@ void dump_work_stats() {
                   "marches per sample\n",
           h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1),
           100.0 * h[51] / (h[40] ? h[40] : 1), h[43] / n);
+  fprintf(stderr, "[work stats] estimate turns per sample that are not the first of their march (of which: found nothing closer "
+                  "than the ground term): primary %.2f (%.2f), reflection %.2f (%.2f), shadow %.2f (%.2f)\n",
+          h[32] / n, h[35] / n, h[33] / n, h[36] / n, h[34] / n, h[37] / n);
   fprintf(stderr, "[work stats] shadow phases with tasks: %.0f, tasks per phase %.1f (%.1f%% without any estimate turn), "
                   "rounds per phase %.2f (%.1f%% of the phases need more than one), rounds of marches WITH estimate turns if the "
                   "others ran apart: %.2f\n",

@@ -275,6 +275,7 @@ struct Tracer {
   // tasks, tasks of that cheap kind  [counted by one lane per wavefront]
   unsigned int ws_sh[6] = {0, 0, 0, 0, 0, 0};
   unsigned int ws_march_est = 0;  // estimate turns of the last march
+  unsigned int ws_k_follow[4] = {0, 0, 0, 0}, ws_k_follow_ground[4] = {0, 0, 0, 0};
   unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
   unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
   RM_DEV unsigned int wave_slots() {
@@ -759,6 +760,12 @@ struct Tracer {
       scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
                      &cut_last);
       last_kind = 1;
+#ifdef RM_WORK_STATS
+      if (ws_march_est >= 2u) {  // not the first real estimate of this march
+        ws_k_follow[ws_kind]++;
+        if (sd == g) ws_k_follow_ground[ws_kind]++;  // ... and it found nothing closer than the ground term
+      }
+#endif
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
       dist += sd;
     }
