@@ -1,0 +1,60 @@
+"""Static guard for the frame kernel's register allocation (no GPU needed: hipcc cross-compiles).
+
+The frame time follows the DYNAMIC spill count: one reload inside a depth-3 loop cost 46 % in
+round 2, and harmless-looking source changes move spills into the march / walk
+loops.  This test compiles the kernels to gfx950 assembly with the product flags and checks, for the
+default instantiation of render_frame_kernel (7 waves/SIMD, row-major tables), where the spills
+sit and that the launch resources are the ones the occupancy argument of DESIGN.md rests on."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0"
+
+
+@pytest.fixture(scope="module")
+def frame_kernel_asm(tmp_path_factory):
+    from raymarchcl_amd import _native
+
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) and not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "k.s"
+    flags = [f for f in _native.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(_native.CSRC, "rm_kernels.hip"),
+                                       "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_spills_stay_out_of_the_inner_loops(frame_kernel_asm):
+    import isa_spills
+
+    res = isa_spills.analyse(frame_kernel_asm.split("\n"), KEY)
+    assert res is not None, "default frame kernel instantiation not found"
+    n_ins, hist, lanes, per_loop = res
+    deep = {d: v for d, v in hist.items() if d >= 3}
+    assert not deep, f"scratch traffic inside depth >= 3 loops: {deep}"
+    at2 = hist.get(2, {"load": 0, "store": 0})
+    assert at2["load"] + at2["store"] <= 4, f"scratch traffic inside depth-2 loops: {at2}"
+    assert 8000 < n_ins < 12000  # the kernel the profiles describe, not a different shape
+
+
+def test_launch_resources_of_the_default_kernel(frame_kernel_asm):
+    # kernel descriptor metadata of the default instantiation
+    m = None
+    for blk in re.finditer(r"- \.agpr_count:.*?\.wavefront_size: +\d+", frame_kernel_asm, re.S):
+        if KEY in blk.group(0):
+            m = blk.group(0)
+    assert m, "metadata block not found"
+    get = lambda k: int(re.search(r"\." + k + r": +(\d+)", m).group(1))
+    assert get("vgpr_count") <= 72          # 7 wavefronts per SIMD
+    assert get("agpr_count") == 0
+    assert get("group_segment_fixed_size") <= 5851  # 160 KB / 28 wavefronts per CU
+    assert get("private_segment_fixed_size") <= 256
+    assert get("wavefront_size") == 64

@@ -56,6 +56,14 @@ def analyse(lines, key):
             if cur:
                 per_loop.setdefault((depth, cur), 0)
                 per_loop[(depth, cur)] += 1
+    return n_ins, hist, lanes, per_loop
+
+
+def report(lines, key):
+    res = analyse(lines, key)
+    if res is None:
+        return
+    n_ins, hist, lanes, per_loop = res
     print(f"{key}: {n_ins} instructions")
     for d in sorted(hist):
         print(f"  loop depth {d}: {hist[d]['load']} scratch loads, {hist[d]['store']} scratch stores")
@@ -70,7 +78,7 @@ def analyse(lines, key):
 def main():
     lines = open(sys.argv[1]).read().split("\n")
     for key in sys.argv[2:]:
-        analyse(lines, key)
+        report(lines, key)
 
 
 if __name__ == "__main__":
