@@ -8,12 +8,13 @@ volume (generators.clj:27-42), 1280x720, 16 passes (spp) with DOF 0.025,
 preset :orange-stripes, camera of the README example -- i.e. the whole
 pipeline of core.clj:76-97 (zeroed accumulator, 16 RenderImage passes in
 order, TonemapImage) with every input already resident in HBM.  With N > 1
-(launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles
+(one rank per GPU: launched by torch.distributed.run, or -- when called as plain
+`python bench.py --gpus N` -- re-launched by this script under it) the frame's 8x8 tiles
 are interleaved over the ranks and the tile accumulators are gathered on rank
 0 over RCCL -- the total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.  `value` = primary rays (= samples) per second
-of the whole job; `roofline` prices the dominant kernel (render_samples_kernel:
+of the whole job; `roofline` prices the dominant kernel (render_frame_kernel:
 all RenderImage passes of the frame in one launch) against HBM bandwidth using
 the ALGORITHMIC bytes of the reference algorithm for that launch (DESIGN.md);
 `cpu_baseline` is the CPU restatement of the reference kernel (oracle/) timed
@@ -106,6 +107,23 @@ def load_traffic(path):
     return j.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this build ({os.path.basename(path)})"
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under
+    torch.distributed.run with one rank per GPU (rank 0 prints the JSON line)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +133,10 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="successive frames alternate between this many HIP streams (1 = strictly serial; "
                          "default 3 on one GPU, 2 per rank on several -- measured best)")
+    ap.add_argument("--backend", default="ranks", choices=["ranks", "library"],
+                    help="ranks: one process per GPU, torch.distributed (RCCL) gather of the tile accumulators; "
+                         "library: ONE process, the frame tiled over N devices inside the C library "
+                         "(rm_create_multi: peer copies over xGMI, no RCCL) -- what a JNI caller gets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
@@ -123,12 +145,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.backend == "ranks":
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "library":
+        sys.exit(library_bench(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -212,16 +236,7 @@ def main():
         value = samples_per_frame * args.steps / elapsed / 1e6
         # algorithmic bytes of the workload: exact event counts from the counting
         # variant of the kernel (same algorithm, +counters), untimed, all passes
-        cnt = _native.Counters()
-        cctx = _native.Context(local_rank)
-        cctx.set_volume(vox, vres)
-        scratch = np.zeros(4 * n, dtype=np.float32)
-        for i in range(spp):
-            cctx.render_image(np.ascontiguousarray(mc[i]), opts[i * 544:(i + 1) * 544], scratch, n=n,
-                              counters=cnt)
-        cctx.close()
-        c = cnt.as_dict()
-        alg_bytes_frame = c["vox_reads"] * 1 + c["mc_reads"] * 16 + samples_per_frame * 32
+        alg_bytes_frame, c = algorithmic_bytes(vox, vres, opts, mc, n, spp, local_rank)
         # one launch covers spp/launches passes of this rank's tiles
         alg_bytes_launch = alg_bytes_frame / launches / world
         achieved = alg_bytes_launch / (pass_ms * 1e-3) / 1e9
@@ -236,7 +251,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "ms_per_frame_serial": round(serial_ms, 4),
+            "ms_per_frame": round(serial_ms, 4),         # the "ms/frame" of the metric: one blocking frame alone
+            "ms_per_frame_serial": round(serial_ms, 4),  # (same number under its round-2 name)
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -293,6 +309,98 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def algorithmic_bytes(vox, vres, opts, mc, n, spp, device=0):
+    """Exact event counts of the REFERENCE algorithm on this workload, from the counting variant
+    of the kernel (same algorithm + counters; identical to the oracle's counters,
+    tests/test_gpu_parity.py), untimed, all passes.  -> (bytes per frame, counters dict)"""
+    from raymarchcl_amd import _native
+
+    cnt = _native.Counters()
+    cctx = _native.Context(device)
+    cctx.set_volume(vox, vres)
+    scratch = np.zeros(4 * n, dtype=np.float32)
+    for i in range(spp):
+        cctx.render_image(np.ascontiguousarray(mc[i]), opts[i * 544:(i + 1) * 544], scratch, n=n, counters=cnt)
+    cctx.close()
+    c = cnt.as_dict()
+    return c["vox_reads"] * 1 + c["mc_reads"] * 16 + n * spp * 32, c
+
+
+def library_bench(args):
+    """--backend library: ONE process; the frame is tiled over N devices inside the C library
+    (rm_create_multi).  Inputs and outputs live in the root device's HBM (rm_frame_device_full);
+    per frame each device renders its interleaved tiles and peer-copies its accumulators into
+    the root (xGMI), which un-permutes + tonemaps.  Frames are enqueued back to back."""
+    import torch
+
+    from raymarchcl_amd import _native
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    rehearsal = os.environ.get("BENCH_ONE_DEVICE", "0") == "1"
+    ids = [0] * args.gpus if rehearsal else list(range(args.gpus))
+    if not rehearsal and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
+    _native.build()
+    wl = WORKLOADS[args.workload]
+    vox, vres, opts, mc = build_inputs(wl)
+    n, width, spp = wl["w"] * wl["h"], wl["w"], wl["spp"]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ctx = _native.Context(ids if len(ids) > 1 else 0)
+    ctx.set_volume(vox, vres)  # replicated to every device of the context
+    d_opts = torch.frombuffer(bytearray(opts), dtype=torch.uint8).to(dev)
+    d_mc = torch.from_numpy(np.ascontiguousarray(mc, dtype=np.float32).reshape(-1)).to(dev)
+    d_px = torch.empty(4 * n, dtype=torch.float32, device=dev)
+    d_argb = torch.empty(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.check_device_opts(d_opts.data_ptr(), spp, n, width)
+
+    def frame():
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), spp, n, width, d_px.data_ptr(), d_argb.data_ptr())
+
+    for _ in range(args.warmup):
+        frame()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms, serial = [], []
+    for _ in range(5):
+        ts = time.perf_counter()
+        frame()
+        ctx.synchronize()
+        serial.append((time.perf_counter() - ts) * 1e3)
+        ms, launches = ctx.last_frame_timing()  # the root's partition
+        kms.append(ms / launches)
+    ctx.close()
+    alg_frame, c = algorithmic_bytes(vox, vres, opts, mc, n, spp)
+    world = len(ids)
+    pass_ms = float(np.median(kms))
+    achieved = alg_frame / launches / world / (pass_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Mrays/s (primary rays = pixel samples per second) + ms/frame, " +
+                  ("256^3 gyroid 1280x720x16spp" if args.workload == "c2" else wl["desc"]),
+        "value": round(n * spp * args.steps / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_frame_serial": round(float(np.median(serial[1:])), 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]], "spp": spp,
+                   "backend": "library (rm_create_multi: one process, peer copies over xGMI, no RCCL)",
+                   "partition": f"8x8 tiles interleaved over {world} device(s)" +
+                                (" (BENCH_ONE_DEVICE rehearsal: every rank on device 0)" if rehearsal and world > 1 else "")},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": "render_frame_kernel (the root device's partition)", "kernel_ms": round(pass_ms, 4),
+                     "launches_per_frame": launches, "alg_bytes_per_launch": int(alg_frame / launches / world),
+                     "alg_bytes_per_sample": round(alg_frame / (n * spp), 1)},
+    }
+    print(json.dumps(out), flush=True)
+    return 0
 
 
 def cpu_baseline(vox, opts, mc, n, spp, passes):

@@ -81,6 +81,17 @@ void rm_destroy(rm_ctx* ctx);
 #define RM_OWN_STREAM ((void*)(intptr_t)-1)
 int rm_set_stream(rm_ctx* ctx, void* hip_stream);
 int rm_synchronize(rm_ctx* ctx);
+/* The reference source casts float seed expressions to uint (renderer.cl:267, 334, 471, 472);
+ * for negative values (about half of all ambient-occlusion seeds) the cast is undefined and
+ * OpenCL devices lower it differently.  RM_SEED_CAST_X86 (default): as an OpenCL CPU device on
+ * x86-64 does (64-bit truncate, low 32 bits: wraps) -- BASELINE config 1's device, and what
+ * the CPU oracle evaluates.  RM_SEED_CAST_GPU: as GPU devices do (gfx950 v_cvt_u32_f32:
+ * saturate, negatives -> 0) -- what the reference kernel compiled for this chip evaluates
+ * (oracle/Makefile ref_gfx950, tools/pin_gfx950.py).  Applies to every later render call of the
+ * context (all devices of a multi-device context). */
+#define RM_SEED_CAST_X86 0
+#define RM_SEED_CAST_GPU 1
+int rm_set_seed_cast(rm_ctx* ctx, int mode);
 
 /* v-buf: vio/load-volume wraps the bytes into a read-only buffer that the
  * pipeline's first step writes to the device (io.clj:29-33, core.clj:81,146).

@@ -4,7 +4,11 @@ ctypes bindings for
   * ``librm_restate.so``  -- our plain-C CPU restatement of the reference render
     path (oracle/rm_restate.c), buildable anywhere, and
   * ``_ref/libref_oracle.so`` -- the UNMODIFIED reference kernel compiled for
-    x86-64 (oracle/Makefile `ref`), only buildable where /root/reference exists.
+    x86-64 (oracle/Makefile `ref`), only buildable where /root/reference exists, and
+  * ``_ref/renderer_gfx950_{fast,default,strict}.hsaco`` -- the same unmodified source
+    compiled for gfx950 and linked against ROCm's own OpenCL built-in library (no stand-in;
+    oracle/Makefile `ref_gfx950`), launched on the GPU through ``libref_gfx950_runner.so``
+    (oracle/ref_gfx950_runner.cpp).
 
 Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 bench.py may import this package.  The product package (raymarchcl_amd) never
@@ -48,7 +52,9 @@ def build(ref=None):
     if ref is None:
         ref = os.path.exists(REFERENCE_CL)
     if ref:
-        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref", "ref_gfx950"])
+    if os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "runner"])
 
 
 _restate = None
@@ -89,6 +95,9 @@ def restate_lib():
                                              ctypes.c_int, ctypes.c_int]
         lib.rmo_render_sdf_frame.restype = None
         lib.rmo_hw_threads.restype = ctypes.c_int
+        lib.rmo_set_seed_cast.argtypes = [ctypes.c_int]
+        lib.rmo_set_seed_cast.restype = None
+        lib.rmo_get_seed_cast.restype = ctypes.c_int
         for name in ("rmo_exp", "rmo_exp2"):
             getattr(lib, name).argtypes = [ctypes.c_float]
             getattr(lib, name).restype = ctypes.c_float
@@ -263,3 +272,83 @@ def ref_tonemap_image(pixels, opts, n=None, fma=False):
     ob = ctypes.create_string_buffer(bytes(opts)[:OPTS_SIZE], OPTS_SIZE)
     ref_lib(fma).ref_tonemap_image(_ptr(pixels, _f32p), ob, _ptr(argb, _u32p), n, 0, n)
     return argb
+
+
+# ---- seed casts: x86-64 lowering (default) or GPU lowering (saturating) ----
+class seed_cast:
+    """``with oracle.seed_cast("gpu"):`` -- the restatement evaluates the (uint) seed casts of
+    renderer.cl:267,334,471,472 as a GPU device does (saturate) instead of as x86-64 does (wrap)."""
+
+    def __init__(self, mode):
+        assert mode in ("x86", "gpu")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = restate_lib().rmo_get_seed_cast()
+        restate_lib().rmo_set_seed_cast(1 if self.mode == "gpu" else 0)
+        return self
+
+    def __exit__(self, *a):
+        restate_lib().rmo_set_seed_cast(self.prev)
+
+
+# ---- the reference kernel compiled for gfx950 (needs a GPU; tests + tools only) ----
+GFX950_BUILDS = ("fast", "default", "strict")
+_gfx = {}
+_runner = None
+
+
+def gfx950_path(build):
+    assert build in GFX950_BUILDS
+    return os.path.join(HERE, "_ref", f"renderer_gfx950_{build}.hsaco")
+
+
+def have_gfx950_ref(build="fast"):
+    return os.path.exists(gfx950_path(build)) and os.path.exists(os.path.join(HERE, "libref_gfx950_runner.so"))
+
+
+def _gfx950_runner():
+    global _runner
+    if _runner is None:
+        # one HIP runtime per process: bind to the copy torch has loaded, as the product library does
+        if os.environ.get("RAYMARCH_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        lib = ctypes.CDLL(os.path.join(HERE, "libref_gfx950_runner.so"))
+        lib.refg_last_error.restype = ctypes.c_char_p
+        lib.refg_load.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.refg_unload.argtypes = [ctypes.c_void_p]
+        lib.refg_unload.restype = None
+        lib.refg_render_frame.argtypes = [ctypes.c_void_p, _u8p, ctypes.c_size_t, _f32p, ctypes.c_void_p,
+                                          ctypes.c_int, _f32p, ctypes.c_int, _u32p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_float)]
+        _runner = lib
+    return _runner
+
+
+def gfx950_render_frame(vox, opts_array, mc_array, n, build="fast", local_size=64, tonemap=True,
+                        pixels_in=None):
+    """The reference kernels themselves (RenderImage per pass, then TonemapImage with record 0) on
+    the GPU, from the code object `build`.  -> (pixels float32[n*4], argb | None, kernel_ms)"""
+    lib = _gfx950_runner()
+    if build not in _gfx:
+        h = ctypes.c_void_p()
+        if lib.refg_load(gfx950_path(build).encode(), ctypes.byref(h)) != 0:
+            raise RuntimeError("gfx950 reference build: " + lib.refg_last_error().decode())
+        _gfx[build] = h
+    iters = len(opts_array) // OPTS_SIZE
+    mc_array = np.ascontiguousarray(mc_array, dtype=np.float32).reshape(-1)
+    assert mc_array.size == iters * TABLE_FLOATS
+    assert vox.dtype == np.uint8 and vox.flags.c_contiguous
+    pixels = np.zeros(n * 4, dtype=np.float32) if pixels_in is None else np.array(pixels_in, dtype=np.float32).reshape(-1)
+    argb = np.zeros(n, dtype=np.uint32) if tonemap else None
+    ms = ctypes.c_float(0.0)
+    ob = ctypes.create_string_buffer(bytes(opts_array), len(opts_array))
+    rc = lib.refg_render_frame(_gfx[build], _ptr(vox, _u8p), vox.size, _ptr(mc_array, _f32p), ob, iters,
+                               _ptr(pixels, _f32p), 0 if pixels_in is None else 1,
+                               _ptr(argb, _u32p) if tonemap else None, n, int(local_size), ctypes.byref(ms))
+    if rc != 0:
+        raise RuntimeError("gfx950 reference build: " + lib.refg_last_error().decode())
+    return pixels, argb, float(ms.value)

@@ -351,9 +351,24 @@ static v3 sky(const ctx_t* c, v3 dir) { return mix3s(c->sky1, c->sky2, dir.y * 0
 /* per-sample state: renderer.cl:27-33 */
 typedef struct { v3 eye; v4 mcPos; v3 mcNormal; float px, py; } sample_t;
 
+/* The (uint) casts of the seed expressions (renderer.cl:267, 334, 471, 472) are undefined for
+ * values outside [0, 2^32).  Default: the x86-64 lowering (cl_f2u: wraps, what an OpenCL CPU
+ * device does).  rmo_set_seed_cast(1): the lowering of GPU devices (gfx950 v_cvt_u32_f32; NVIDIA
+ * cvt.rzi.u32.f32): saturate to [0, 2^32 - 1], NaN -> 0 -- used to compare with the reference
+ * kernel compiled for gfx950 (oracle/_ref/renderer_gfx950_*.hsaco). */
+static int g_seed_cast_gpu = 0;
+void rmo_set_seed_cast(int gpu) { g_seed_cast_gpu = gpu; }
+int rmo_get_seed_cast(void) { return g_seed_cast_gpu; }
+static inline uint32_t seed_cast(float x) {
+  if (!g_seed_cast_gpu) return cl_f2u(x);
+  if (!(x > 0.0f)) return 0u;            /* negatives, -0, NaN */
+  if (x >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)x;
+}
+
 /* jittered light position: renderer.cl:263-269 (one seed for all lights of a sample) */
 static v3 light_at(ctx_t* c, const sample_t* s, int i) {
-  const uint32_t seed = cl_f2u(s->px * 1957.0f + s->py * 2173.0f + c->time * 4763.742f);
+  const uint32_t seed = seed_cast(s->px * 1957.0f + s->py * 2173.0f + c->time * 4763.742f);
   const v4 r = table(c, seed);
   return mad3s(V(r.x, r.y, r.z), c->lightScatter, light_pos_opt(c, i));
 }
@@ -409,7 +424,7 @@ static float occlusion(ctx_t* c, v3 pos, v3 normal) {
   c->st.ao_calls++;
   float ao = 1.0f;
   float d = 0.0f;
-  uint32_t seed = cl_f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + c->time * 2671.918f);
+  uint32_t seed = seed_cast(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + c->time * 2671.918f);
   for (int i = 0; i <= c->aoIter && (double)ao > 0.01; i++) {
     d += c->aoStepDist;
     seed += 37u;
@@ -503,8 +518,8 @@ static v3 sample_colour(ctx_t* c, const sample_t* s, v3 ro, v3 rd) {
 static sample_t sample_init(ctx_t* c, int id) {
   sample_t s;
   const float fx = (float)(id % c->resx), fy = (float)(id / c->resx);
-  s.mcPos = table(c, (uint32_t)id * 17u + cl_f2u(c->time * 3141.3862f));
-  const v4 t = table(c, (uint32_t)id * 37u + cl_f2u(c->time * 1859.1467f));
+  s.mcPos = table(c, (uint32_t)id * 17u + seed_cast(c->time * 3141.3862f));
+  const v4 t = table(c, (uint32_t)id * 37u + seed_cast(c->time * 1859.1467f));
   s.mcNormal = normalize3(V(t.x, t.y, t.z));
   s.px = fx + s.mcPos.z;
   s.py = fy + s.mcPos.w;

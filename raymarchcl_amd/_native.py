@@ -27,7 +27,7 @@ TABLE_FLOATS = 0x4000 * 4
 # every symbol include/raymarch_hip.h declares
 EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_create_multi", "rm_num_devices",
-    "rm_destroy", "rm_set_stream", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
     "rm_invalidate_volume", "rm_share_volume", "rm_frame_device_full", "rm_last_table_build_ms",
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
@@ -119,6 +119,7 @@ def lib():
     L.rm_destroy.restype = None
     L.rm_set_stream.argtypes = [_vp, _vp]
     L.rm_synchronize.argtypes = [_vp]
+    L.rm_set_seed_cast.argtypes = [_vp, _i]
     L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
@@ -261,6 +262,11 @@ class Context:
 
     def synchronize(self):
         check(lib().rm_synchronize(self._h))
+
+    def set_seed_cast(self, mode):
+        """"x86" (default): the undefined (uint) casts of the seed expressions as an OpenCL CPU
+        device lowers them; "gpu": as GPU devices do (include/raymarch_hip.h rm_set_seed_cast)."""
+        check(lib().rm_set_seed_cast(self._h, {"x86": 0, "gpu": 1}[mode]))
 
     # -- kernel-level entry points (host buffers) -------------------------
     @staticmethod

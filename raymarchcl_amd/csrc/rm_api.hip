@@ -100,13 +100,20 @@ struct rm_ctx {
   int waves_per_simd = 7;    // RAYMARCH_WAVES_PER_SIMD (4..8): register budget of the frame kernel
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
+  int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
   // records validated by rm_check_device_opts
   std::vector<RmOpts> dev_recs;
   std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
   const void* dev_src = nullptr;
   int dev_iter = 0, dev_n = 0, dev_width = 0;
   unsigned long long dev_generation = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_in = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_in = nullptr,
+             ev_resolved = nullptr;
+  bool resolved_once = false;
+  // multi-device contexts: the device inputs last replicated to the other devices
+  const void* repl_opts = nullptr;
+  const void* repl_mc = nullptr;
+  int repl_iter = 0;
   bool timed = false;
   int launches = 0;
   // rm_create_multi: the other devices of a multi-device context (this one is rank 0)
@@ -254,7 +261,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   if (rc) return rc;
   HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
-                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt));
+                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt, c->seed_cast));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
   rm_counters got{};
   if (counters)
@@ -310,6 +317,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.xcd_rows = c->xcd_rows;
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
+    f.seed_cast_gpu = c->seed_cast;
     HIP_TRY(rmk::launch_render_frame(c->stream, f));
     launches++;
     i0 = i1;
@@ -376,6 +384,7 @@ static int create_one(int device_id, rm_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_resolved, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b1);
   if (e != hipSuccess) {
@@ -466,6 +475,7 @@ void rm_destroy(rm_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_resolved) (void)hipEventDestroy(c->ev_resolved);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
   if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -476,6 +486,14 @@ int rm_set_stream(rm_ctx* c, void* hip_stream) {
   int rc = check_ctx(c);
   if (rc) return rc;
   c->stream = hip_stream == RM_OWN_STREAM ? c->own_stream : static_cast<hipStream_t>(hip_stream);
+  return RM_OK;
+}
+
+int rm_set_seed_cast(rm_ctx* c, int mode) {
+  if (!c) return fail(RM_EINVAL, "rm_ctx is NULL");
+  if (mode != RM_SEED_CAST_X86 && mode != RM_SEED_CAST_GPU) return fail(RM_EINVAL, "unknown seed cast mode %d", mode);
+  c->seed_cast = mode;
+  for (rm_ctx* p : c->peers) p->seed_cast = mode;
   return RM_OK;
 }
 
@@ -523,6 +541,8 @@ static int broadcast_volume(rm_ctx* c) {
     int rc = begin_new_volume(p, true);
     if (rc) return rc;
     Volume& pv = *p->vol;
+    pv.d_vox = nullptr;  // published again only once the copy has succeeded
+    pv.rx = pv.ry = pv.rz = 0;
     HIP_TRY(pv.vox_buf.reserve(bytes));
     HIP_TRY(hipMemcpyPeerAsync(pv.vox_buf.p, p->device, v.d_vox, c->device, bytes, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -543,6 +563,9 @@ int rm_set_volume(rm_ctx* c, const uint8_t* voxels, int rx, int ry, int rz) {
   rc = begin_new_volume(c, true);
   if (rc) return rc;
   Volume& v = *c->vol;
+  // (a failed allocation or copy must not leave the old pointer behind: reserve() frees first)
+  v.d_vox = nullptr;
+  v.rx = v.ry = v.rz = 0;
   HIP_TRY(v.vox_buf.reserve(bytes));
   HIP_TRY(hipMemcpyAsync(v.vox_buf.p, voxels, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -729,46 +752,49 @@ static int upload_frame_inputs(rm_ctx* c, const void* opts_array, const float* m
   return RM_OK;
 }
 
-// rm_render_frame over the devices of a multi-device context: device r renders the image
-// tiles r, r+N, ... (interleaved: cost per tile is very uneven) into tile-major accumulators,
-// the root collects them with one peer copy per device (xGMI, all links into the root
-// concurrently) and un-permutes + tonemaps.
-static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
-                              const RmOpts* recs, const unsigned char* same, float* pixels_out,
-                              uint32_t* argb_out, bool sdf) {
+// One frame over the devices of a multi-device context, inputs and outputs in the ROOT's
+// device memory: device r renders the image tiles r, r+N, ... (interleaved: cost per tile is
+// very uneven) into tile-major accumulators, the root collects them with one peer copy per
+// device (xGMI, all links into the root concurrently) and un-permutes + tonemaps.
+// Asynchronous: everything is ordered by events, the host only enqueues.
+//   replicate: copy the records and tables from the root to the other devices first (they
+//   keep them in their own opts_buf / mc_buf; a caller whose inputs did not change skips it)
+static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, bool replicate, int iter, int n,
+                              const RmOpts* recs, const unsigned char* same, float* d_pixels, uint32_t* d_argb,
+                              bool sdf) {
   const int world = 1 + (int)c->peers.size();
   const int resx = recs[0].resolution[0];
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), world);
   const size_t part_bytes = (size_t)tpp * 64 * 16;
   HIP_TRY(c->tile_buf.reserve(part_bytes * world));
-  // the records and tables cross PCIe once, to the root; the other devices take them from
-  // there over xGMI (asynchronous: the host gets all n launches out without waiting for n uploads)
-  {
-    int rc = upload_frame_inputs(c, opts_array, mc_array, iter);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->ev_in, c->stream));
-  }
   const size_t opts_bytes = (size_t)iter * RM_OPTS_BYTES, mc_bytes = (size_t)iter * RM_TABLE_FLOATS * 4;
+  if (replicate) HIP_TRY(hipEventRecord(c->ev_in, c->stream));  // the root's inputs are complete here
   for (int r = 0; r < world; r++) {
     rm_ctx* d = r == 0 ? c : c->peers[r - 1];
     HIP_TRY(hipSetDevice(d->device));
+    const RmOpts* my_opts = d_opts;
+    const float* my_mc = d_mc;
     if (r > 0) {
-      HIP_TRY(d->opts_buf.reserve(opts_bytes));
-      HIP_TRY(d->mc_buf.reserve(mc_bytes));
-      HIP_TRY(hipStreamWaitEvent(d->stream, c->ev_in, 0));
-      HIP_TRY(hipMemcpyPeerAsync(d->opts_buf.p, d->device, c->opts_buf.p, c->device, opts_bytes, d->stream));
-      HIP_TRY(hipMemcpyPeerAsync(d->mc_buf.p, d->device, c->mc_buf.p, c->device, mc_bytes, d->stream));
+      if (replicate) {
+        HIP_TRY(d->opts_buf.reserve(opts_bytes));
+        HIP_TRY(d->mc_buf.reserve(mc_bytes));
+        HIP_TRY(hipStreamWaitEvent(d->stream, c->ev_in, 0));
+        HIP_TRY(hipMemcpyPeerAsync(d->opts_buf.p, d->device, d_opts, c->device, opts_bytes, d->stream));
+        HIP_TRY(hipMemcpyPeerAsync(d->mc_buf.p, d->device, d_mc, c->device, mc_bytes, d->stream));
+      }
+      my_opts = static_cast<const RmOpts*>(d->opts_buf.p);
+      my_mc = static_cast<const float*>(d->mc_buf.p);
+      HIP_TRY(d->tile_buf.reserve(part_bytes));
     }
-    int rc = RM_OK;
     FrameOut out;
-    if (r > 0) HIP_TRY(d->tile_buf.reserve(part_bytes));
     out.acc = static_cast<float*>(r == 0 ? c->tile_buf.p : d->tile_buf.p);
     out.tile_first = r;
     out.tile_stride = world;
-    rc = frame_on_device(d, static_cast<const RmOpts*>(d->opts_buf.p), static_cast<const float*>(d->mc_buf.p),
-                         resx, iter, n, out, same, recs, sdf);
+    int rc = frame_on_device(d, my_opts, my_mc, resx, iter, n, out, same, recs, sdf);
     if (rc) return rc;
     if (r > 0) {
+      // the root's gather buffer is free once the previous frame's resolve has read it
+      if (c->resolved_once) HIP_TRY(hipStreamWaitEvent(d->stream, c->ev_resolved, 0));
       HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(c->tile_buf.p) + part_bytes * r, c->device, d->tile_buf.p,
                                  d->device, part_bytes, d->stream));
       HIP_TRY(hipEventRecord(d->ev_done, d->stream));
@@ -776,13 +802,25 @@ static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc
   }
   HIP_TRY(hipSetDevice(c->device));
   for (rm_ctx* p : c->peers) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_done, 0));
+  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp, d_opts, d_pixels,
+                              d_argb, n));
+  HIP_TRY(hipEventRecord(c->ev_resolved, c->stream));
+  c->resolved_once = true;
+  return RM_OK;
+}
+
+// rm_render_frame (host buffers) over the devices of a multi-device context: the records and
+// tables cross PCIe once, to the root; the other devices take them from there over xGMI
+static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
+                              const RmOpts* recs, const unsigned char* same, float* pixels_out,
+                              uint32_t* argb_out, bool sdf) {
+  int rc = upload_frame_inputs(c, opts_array, mc_array, iter);
+  if (rc) return rc;
   if (pixels_out) HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
   if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
-  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp,
-                              static_cast<const RmOpts*>(c->opts_buf.p),
-                              pixels_out ? static_cast<float*>(c->pix_buf.p) : nullptr,
-                              argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr, n));
-  return RM_OK;
+  return frame_multi_device(c, static_cast<const RmOpts*>(c->opts_buf.p), static_cast<const float*>(c->mc_buf.p), true,
+                            iter, n, recs, same, pixels_out ? static_cast<float*>(c->pix_buf.p) : nullptr,
+                            argb_out ? static_cast<uint32_t*>(c->argb_buf.p) : nullptr, sdf);
 }
 
 static int render_frame_host(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
@@ -891,6 +929,7 @@ int rm_check_device_opts(rm_ctx* c, const void* d_opts, int iter, int n, int wid
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->dev_src = nullptr;
+  c->repl_opts = nullptr;  // (multi-device: the next frame replicates records and tables again)
   rc = check_frame_opts(c, recs.data(), iter, n, width);
   if (rc) return rc;
   records_same_as_prev(recs.data(), iter, &c->dev_same);
@@ -945,6 +984,15 @@ int rm_frame_device_full(rm_ctx* c, const void* d_opts, const float* d_mc, int i
   if (iter <= 0 || n <= 0 || width <= 0) return fail(RM_EINVAL, "iter = %d, n = %d, width = %d", iter, n, width);
   rc = check_validated(c, d_opts, iter, n, width);
   if (rc) return rc;
+  if (!c->peers.empty()) {
+    // the frame tiled over all devices of the context; the records and tables (in the root's
+    // memory) go to the other devices once per validation (rm_check_device_opts) / per new d_mc
+    const bool repl = c->repl_opts != d_opts || c->repl_mc != d_mc || c->repl_iter != iter;
+    rc = frame_multi_device(c, static_cast<const RmOpts*>(d_opts), d_mc, repl, iter, n, c->dev_recs.data(),
+                            c->dev_same.data(), d_pixels, d_argb, false);
+    if (rc == RM_OK) { c->repl_opts = d_opts; c->repl_mc = d_mc; c->repl_iter = iter; }
+    return rc;
+  }
   FrameOut out;
   if (!d_pixels) HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
   out.acc = d_pixels ? d_pixels : static_cast<float*>(c->pix_buf.p);

@@ -13,13 +13,17 @@
 // x86-64 lowering (what "OpenCL CPU device" means for BASELINE config 1):
 //   f2i: truncate; NaN / out of int32 range -> INT_MIN      (cvttss2si r32)
 //   f2u: 64-bit truncate, low 32 bits; NaN / |x|>=2^63 -> 0 (cvttss2si r64)
-// gfx950's native v_cvt_u32_f32 would saturate negatives to 0 instead
-// (SURVEY F6); build with -DRM_SEED_CAST_SATURATE to get that behaviour.
+// gfx950's native v_cvt_u32_f32 saturates instead (negatives -> 0) -- which is what
+// the reference kernel compiled for a GPU device does: f2u_gpu(), selected per context with
+// rm_set_seed_cast(ctx, RM_SEED_CAST_GPU).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
 #define RM_DEV __device__ __forceinline__
+#ifndef RM_F2U_GPU_ASM
+#define RM_F2U_GPU_ASM 0
+#endif
 
 namespace rmd {
 
@@ -33,10 +37,21 @@ RM_DEV int32_t f2i(float x) {
   if (!(x >= -2147483648.0f && x < 2147483648.0f)) return INT32_MIN;
   return (int32_t)x;
 }
-RM_DEV uint32_t f2u(float x) {
-#ifdef RM_SEED_CAST_SATURATE
-  return (uint32_t)x;
+RM_DEV uint32_t f2u_gpu(float x) {
+  // what v_cvt_u32_f32 does -- truncate, saturate to [0, 2^32 - 1], NaN -> 0 -- written so that no
+  // C cast is out of range (the compiler folds the comparisons around one v_cvt_u32_f32)
+#if RM_F2U_GPU_ASM
+  // REPRODUCER ONLY (tools/repro_gpucast_fault.sh): the instruction itself through inline asm.
+  // With this form the 6- and 7-waves/SIMD instantiations of the accelerated frame kernel render
+  // ~80 % of the pixels wrong while 5 and 8 are right -- never the product.
+  uint32_t r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 #else
+  return x > 0.0f ? (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x) : 0u;
+#endif
+}
+RM_DEV uint32_t f2u(float x) {
   if (!(x >= -9223372036854775808.0f && x < 9223372036854775808.0f)) return 0u;
   // |x| < 2^63: split so that only 32-bit hardware conversions are needed.
   // trunc(x) = hi*2^32 + lo exactly (both parts are exact floats); the low 32
@@ -47,7 +62,6 @@ RM_DEV uint32_t f2u(float x) {
   const float lo = a - hi * 4294967296.0f;                         // exact: a, hi*2^32 share the grid
   const uint32_t m = (uint32_t)lo;                                  // 0 <= lo < 2^32
   return t < 0.0f ? (0u - m) : m;
-#endif
 }
 RM_DEV int32_t convert_int_sat(float x) {
   // OpenCL convert_int_sat(float): truncate, saturate, NaN -> 0 -- which is exactly

@@ -33,7 +33,7 @@ hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, i
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters);
+                              Counters* d_counters, int seed_cast_gpu = 0);
 // One launch of the frame kernel (rm_kernels.hip render_frame_kernel): `passes` consecutive
 // RenderImage passes over partition (tile_first, tile_stride) of the image, blended in order
 // into `acc`.  pp_log2 > 0: a wavefront holds 2^pp_log2 passes of 64/2^pp_log2 pixels -- only
@@ -50,6 +50,7 @@ struct FrameLaunch {
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int min_waves = 7, pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
+  int seed_cast_gpu = 0;           // rm_set_seed_cast
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
 int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);

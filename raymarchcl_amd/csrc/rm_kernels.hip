@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
     const RmOpts* __restrict__ opts,
     float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
-    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0) {
+    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0, int seed_cast_gpu = 0) {
   const int resx = opts->resolution[0];
   const TileGeom g = tile_geom(resx, n);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   if (tile >= g.tiles_total) return;
   const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
   rmk::Scene sc{vox, mc, opts, dist8, surf32, oct_stride};
+  sc.seed_cast_gpu = seed_cast_gpu;
   rmk::Tracer<COUNT, ACCEL, false, BRICK> tr(sc);
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
@@ -149,9 +150,9 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 #ifndef RM_PERSISTENT
 #define RM_PERSISTENT 0  // A/B: a resident grid whose wavefronts stride over the frame's blocks
 #endif
-template <bool ACCEL, bool SDFM, bool MULTI, bool BRICK>
+template <bool ACCEL, bool SDFM, bool MULTI, bool BRICK, bool GPUCAST>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
-  using Tr = rmk::Tracer<false, ACCEL, SDFM, BRICK>;
+  using Tr = rmk::Tracer<false, ACCEL, SDFM, BRICK, GPUCAST ? 1 : 0>;
   const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
@@ -269,18 +270,18 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
 #endif
 }
 
-template <bool ACCEL, int MINW, bool SDFM, bool MULTI, bool BRICK = false>
+template <bool ACCEL, int MINW, bool SDFM, bool MULTI, bool BRICK = false, bool GPUCAST = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
   __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
 #if RM_PERSISTENT
   // (stride = grid size, a multiple of 8: a wavefront stays on the tile rows of its XCD)
   for (long long b = blockIdx.x; b < a.total_blocks; b += gridDim.x) {
-    frame_block<ACCEL, SDFM, MULTI, BRICK>(a, b, wave_lds);
+    frame_block<ACCEL, SDFM, MULTI, BRICK, GPUCAST>(a, b, wave_lds);
     __syncthreads();
   }
 #else
-  frame_block<ACCEL, SDFM, MULTI, BRICK>(a, blockIdx.x, wave_lds);
+  frame_block<ACCEL, SDFM, MULTI, BRICK, GPUCAST>(a, blockIdx.x, wave_lds);
 #endif
 }
 
@@ -451,7 +452,7 @@ void dump_work_stats() {
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters) {
+                              Counters* d_counters, int seed_cast_gpu) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const long long my_tiles =
@@ -465,7 +466,7 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
 #define RM_LAUNCH(C, T, A, B)                                                                      \
   render_pass_kernel<C, T, A, B><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, \
                                                          px4, n, id0, id1, tile_first, tile_stride, \
-                                                         d_counters, accel.oct_stride)
+                                                         d_counters, accel.oct_stride, seed_cast_gpu)
   if (d_counters) RM_LAUNCH(true, false, false, false);
   else if (acc && accel.bricked) { if (tile_major) RM_LAUNCH(false, true, true, true); else RM_LAUNCH(false, false, true, true); }
   else if (tile_major && acc) RM_LAUNCH(false, true, true, false);
@@ -533,26 +534,32 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
 #endif
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   const bool multi = f.passes > (1 << pp_log2);
-#define RM_FRAME(A, W, S, B)                                                     \
-  do {                                                                           \
-    if (multi) render_frame_kernel<A, W, S, true, B><<<grid, block, 0, st>>>(a);  \
-    else render_frame_kernel<A, W, S, false, B><<<grid, block, 0, st>>>(a);       \
+#define RM_FRAME(A, W, S, B, G)                                                     \
+  do {                                                                              \
+    if (multi) render_frame_kernel<A, W, S, true, B, G><<<grid, block, 0, st>>>(a);  \
+    else render_frame_kernel<A, W, S, false, B, G><<<grid, block, 0, st>>>(a);       \
   } while (0)
+  const bool gpucast = f.seed_cast_gpu != 0;
   if (f.sdf) {
-    RM_FRAME(false, 4, true, false);
+    if (gpucast) RM_FRAME(false, 4, true, false, true); else RM_FRAME(false, 4, true, false, false);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
     // (volumes whose tables exceed the caches: one register budget, the default)
-    RM_FRAME(true, 7, false, true);
+    if (gpucast) RM_FRAME(true, 7, false, true, true); else RM_FRAME(true, 7, false, true, false);
   } else if (f.accel.dist && f.accel.surf) {
-    switch (f.min_waves) {
-      case 4: RM_FRAME(true, 4, false, false); break;
-      case 5: RM_FRAME(true, 5, false, false); break;
-      case 6: RM_FRAME(true, 6, false, false); break;
-      case 8: RM_FRAME(true, 8, false, false); break;
-      default: RM_FRAME(true, 7, false, false); break;
+    if (gpucast) {  // (one register budget for the GPU-cast mode)
+#ifndef RM_GPUCAST_MINW
+#define RM_GPUCAST_MINW 7
+#endif
+      RM_FRAME(true, RM_GPUCAST_MINW, false, false, true);
+    } else switch (f.min_waves) {
+      case 4: RM_FRAME(true, 4, false, false, false); break;
+      case 5: RM_FRAME(true, 5, false, false, false); break;
+      case 6: RM_FRAME(true, 6, false, false, false); break;
+      case 8: RM_FRAME(true, 8, false, false, false); break;
+      default: RM_FRAME(true, 7, false, false, false); break;
     }
   } else {
-    RM_FRAME(false, 3, false, false);
+    if (gpucast) RM_FRAME(false, 3, false, false, true); else RM_FRAME(false, 3, false, false, false);
   }
 #undef RM_FRAME
   return hipGetLastError();

@@ -56,6 +56,7 @@ struct Scene {
   unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
   const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
   const uint8_t* __restrict__ coarse = nullptr;  // RM_COARSE A/B: 4^3-block minima of the tables
+  int seed_cast_gpu = 0;  // (uint) casts of the seed expressions as a GPU device lowers them (rm_set_seed_cast)
 };
 #ifndef RM_COARSE
 #define RM_COARSE 0
@@ -234,15 +235,18 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 #ifndef RM_LAZY_NORMAL
 #define RM_LAZY_NORMAL 1  // primary / reflection marches: walks reach as far as the ground term; last turn repeated if cut
 #endif
-#ifndef RM_INSIDE_TEST
 #ifndef RM_DARK_SKIP
 #define RM_DARK_SKIP 1    // shadow marches whose result is multiplied by exact zeros are not traced
 #endif
+#ifndef RM_INSIDE_TEST
 #define RM_INSIDE_TEST 1  // skip the slab test when the position is inside the box by a margin
 #endif
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
 // come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
-template <bool COUNT, bool ACCEL = false, bool SDFM = false, bool BRICK = false>
+// CAST: lowering of the undefined (uint) seed casts -- 0: x86-64 (wrap), 1: GPU (saturate),
+// 2: chosen at run time by Scene::seed_cast_gpu (the single-pass parity kernels; the frame kernel
+// is instantiated per mode so that the flag costs its hot code nothing)
+template <bool COUNT, bool ACCEL = false, bool SDFM = false, bool BRICK = false, int CAST = 2>
 struct Tracer {
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
   static_assert(!(SDFM && (COUNT || ACCEL)), "the quality mode has no counters and no derived tables");
@@ -309,6 +313,13 @@ struct Tracer {
     time_ = time_of_pass;
   }
 
+  // the (uint) cast of a seed expression (renderer.cl:267, 334, 471, 472): undefined outside
+  // [0, 2^32); x86-64 lowering by default, GPU lowering on request (uniform branch)
+  RM_DEV uint32_t seed_of(float x) {
+    if (CAST == 0) return rmd::f2u(x);
+    if (CAST == 1) return rmd::f2u_gpu(x);
+    return sc.seed_cast_gpu ? rmd::f2u_gpu(x) : rmd::f2u(x);
+  }
   // scatter table lookup: renderer.cl:142-144
   RM_DEV float4 table(uint32_t seed) {
     if (COUNT) cnt.mc_reads++;
@@ -799,7 +810,7 @@ struct Tracer {
   // jittered light position: renderer.cl:263-269
   RM_DEV v3 light_at(const Sample& s, int i) {
     const RmOpts& o = *sc.o;
-    const uint32_t seed = rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
+    const uint32_t seed = seed_of(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
     const float4 r = table(seed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
@@ -843,7 +854,7 @@ struct Tracer {
     RM_WS(ws_probes++);
     float d = 0.0f;
     uint32_t seed =
-        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+        seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
     for (int i = 0; i <= o.aoIter && (double)ao > 0.01; i++) {
       d += o.aoStepDist;
       seed += 37u;
@@ -950,8 +961,8 @@ struct Tracer {
     s.time = time_;
     const int resx = o.resolution[0];
     const float fx = (float)(id % resx), fy = (float)(id / resx);
-    const float4 mcPos = table((uint32_t)id * 17u + rmd::f2u(time_ * 3141.3862f));
-    const float4 t = table((uint32_t)id * 37u + rmd::f2u(time_ * 1859.1467f));
+    const float4 mcPos = table((uint32_t)id * 17u + seed_of(time_ * 3141.3862f));
+    const float4 t = table((uint32_t)id * 37u + seed_of(time_ * 1859.1467f));
     s.mcNormal = normalize(V(t.x, t.y, t.z));
     s.px = fx + mcPos.z;
     s.py = fy + mcPos.w;
@@ -1029,7 +1040,7 @@ struct Tracer {
     if (dl.owners == 0) return 1.0f;
     if (np > kWaveLdsRes) return active ? occlusion(s, pos, normal) : 1.0f;  // (uniform) too many probes to post
     const uint32_t seed0 =
-        rmd::f2u(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+        seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
     if (active) {
       RM_WS(ws_probes++);
       lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
@@ -1205,7 +1216,7 @@ struct Tracer {
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
-      const float4 r = table(rmd::f2u(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
+      const float4 r = table(seed_of(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
       jit = V(r.x, r.y, r.z);
     }
 #ifdef RM_PHASE_CLOCK

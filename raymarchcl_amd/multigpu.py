@@ -138,6 +138,13 @@ class FrameRenderer:
         root = rank == 0
         self.slots = []
         nslots = max(1, int(frames_in_flight))
+        # The tables derived from the volume are built per (volume, isoVal) and rebuilt IN PLACE when
+        # a launch needs another isoVal (rm_share_volume's rule: sharers must not render with
+        # different thresholds at the same time).  Records of one frame may differ in isoVal; slots
+        # in flight would then rebuild the tables under each other's launches -- such a frame gives
+        # every slot its own volume context (and its own tables) instead of sharing.
+        iso = {opts_bytes[i * _native.OPTS_BYTES + 284] for i in range(self.iters)}
+        self.shared_tables = len(iso) == 1
         for i in range(nslots):
             # One frame at a time: torch's current stream (what a caller with its own stream
             # expects).  Several: streams created here back to back -- HIP deals streams to its
@@ -145,7 +152,7 @@ class FrameRenderer:
             # caller's stream may share one with them (two slots on one queue do not overlap).
             stream = torch.cuda.current_stream(dev) if nslots == 1 else torch.cuda.Stream(dev)
             slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb, world)
-            if i == 0:
+            if i == 0 or not self.shared_tables:
                 slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
             else:
                 slot.ctx.share_volume(self.slots[0].ctx)

@@ -1,0 +1,101 @@
+"""The parity chain pinned to the reference kernel itself, compiled for THIS chip with no
+stand-in: the unmodified renderer.cl -> gfx950 code objects linked against ROCm's own OpenCL
+built-in library (oracle/Makefile `ref_gfx950`; prebuilt in the build container, git-ignored,
+travels with the snapshot like every other built file), launched through hipModuleLoad
+(oracle/ref_gfx950_runner.cpp) exactly as core.clj:76-97 sequences the kernels.
+
+What can and cannot be asserted: the reference source leaves rounding to the OpenCL compiler
+(core.clj:128 builds with :fast-math :enable-mad), and every re-rounding flips hit/miss decisions
+of a few pixels -- the three reference builds disagree with EACH OTHER on ~1-2 % of
+the pixels.  So the tests assert (a) bit-exactness of the HIP path against the CPU oracle in the
+GPU cast mode too, (b) BASELINE's metric -- the fraction of pixels within 1e-4 relative -- of
+the HIP path against each reference build, which must be as good as the agreement of the
+reference builds among themselves, and ~100 % on the pixels where those builds agree.
+Numbers: profiles/r03_pin_gfx950.txt (tools/pin_gfx950.py)."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.reshape(-1, 4)[:, :3].astype(np.float64)
+    b = b.reshape(-1, 4)[:, :3].astype(np.float64)
+    r = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+    return r.max(axis=1)
+
+
+@pytest.fixture(scope="module")
+def refs(oracle_mod):
+    if not oracle_mod.have_gfx950_ref("fast"):
+        pytest.skip("oracle/_ref/renderer_gfx950_*.hsaco not built (needs /root/reference: build container)")
+    return oracle_mod
+
+
+CASES = {
+    "c1": dict(scenes.SCENES["c1_orange"], w=256, h=256),
+    "c2_geometry": dict(vol="gyroid", vres=256, w=320, h=180, iter=4, mat="orange-stripes", theta=-45, dist=2.25,
+                        dof=0.025),
+    "metal_bounces": dict(scenes.SCENES["metal_3spp"], w=128, h=96),
+}
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def rendered(request, refs, native):
+    sc = scenes.build(CASES[request.param])
+    n = sc["n"]
+    ref = {b: refs.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], n, build=b)[:2] for b in refs.GFX950_BUILDS}
+    hip = {}
+    with native.Context(0) as ctx:
+        ctx.set_volume(sc["vox"], sc["vres"])
+        for mode in ("x86", "gpu"):
+            ctx.set_seed_cast(mode)
+            hip[mode] = ctx.render_frame(sc["opts"], sc["mc"], n)
+    return request.param, sc, ref, hip
+
+
+def test_reference_kernels_run_and_tonemap_agrees(rendered, refs):
+    """RenderImage / TonemapImage of the code objects execute (OpenCL kernarg layout + hidden
+    arguments filled from the metadata) and produce a real image; TonemapImage of the strict build
+    equals the oracle's tonemap of the same accumulator."""
+    name, sc, ref, hip = rendered
+    for b, (px, argb) in ref.items():
+        p = px.reshape(-1, 4)
+        assert np.isfinite(p).all() and (p[:, 3] == 1.0).all(), b
+        assert p[:, :3].std() > 0.05, b
+        assert (argb >> 24 == 0xff).all(), b
+    px, argb = ref["strict"]
+    want = refs.tonemap_image(px.copy(), sc["opts"][:544])
+    assert (want != argb).mean() < 1e-3  # (division / multiply order of the device build: a handful of 1-LSB channels)
+
+
+def test_hip_equals_oracle_in_both_cast_modes(rendered, refs):
+    name, sc, ref, hip = rendered
+    for mode in ("x86", "gpu"):
+        with refs.seed_cast(mode):
+            want_px, want_argb = refs.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+        got_px, got_argb = hip[mode]
+        assert np.array_equal(got_px.view(np.uint32), want_px.view(np.uint32)), mode
+        assert np.array_equal(got_argb, want_argb), mode
+    # the modes do differ (about half of the AO seeds are negative)
+    assert not np.array_equal(hip["x86"][0], hip["gpu"][0])
+
+
+def test_metric_against_every_reference_build(rendered, refs):
+    """BASELINE's parity metric of the HIP path (GPU cast mode = the casts of these code objects)
+    against each reference build, next to the agreement of the reference builds among themselves."""
+    name, sc, ref, hip = rendered
+    px = {b: ref[b][0] for b in ref}
+    stable = (rel(px["fast"], px["strict"]) <= 1e-4) & (rel(px["fast"], px["default"]) <= 1e-4) & \
+             (rel(px["default"], px["strict"]) <= 1e-4)
+    among = min((rel(px[a], px[b]) <= 1e-4).mean() for a in px for b in px if a < b)
+    got = hip["gpu"][0]
+    for b in px:
+        r = rel(got, px[b])
+        frac, frac_stable = (r <= 1e-4).mean(), (r[stable] <= 1e-4).mean()
+        print(f"{name}: HIP gpu-cast vs `{b}`: {100 * frac:.3f} % within 1e-4 ({100 * frac_stable:.3f} % of the stable "
+              f"pixels; reference builds among themselves: {100 * among:.3f} %)")
+        assert frac >= among - 0.01, (b, frac, among)
+        assert frac_stable >= 0.995, (b, frac_stable)

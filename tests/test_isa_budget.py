@@ -15,15 +15,15 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0"
+KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0ELb0"
 
 
 @pytest.fixture(scope="module")
 def frame_kernel_asm(tmp_path_factory):
     from raymarchcl_amd import _native
 
-    hipcc = "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc) and not shutil.which("hipcc"):
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
         pytest.skip("no hipcc")
     out = tmp_path_factory.mktemp("isa") / "k.s"
     flags = [f for f in _native.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Pin the parity chain to the reference kernel built for THIS chip with no stand-in.
+
+`make -C oracle ref_gfx950` compiles the unmodified /root/reference/resources/renderer.cl for
+gfx950 with ROCm's OpenCL front end; the clang driver links ROCm's own OpenCL built-in library
+(opencl.bc / ocml.bc / ockl.bc / oclc_*.bc).  Three code objects:
+
+    fast     -cl-fast-relaxed-math -cl-mad-enable   = the reference's own build options (core.clj:128)
+    default  no options                             = OpenCL defaults (contraction on, 2.5-ulp divide)
+    strict   -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt
+
+This tool (GPU box) runs them through oracle/ref_gfx950_runner.cpp exactly as the reference host
+does (RenderImage per pass on a zeroed accumulator, core.clj:76-97) and reports BASELINE.json's
+parity metric -- fraction of pixels whose r,g,b all lie within 1e-4 relative -- for
+
+    HIP x86-cast   the product library as shipped (seed casts as an OpenCL CPU device lowers them)
+    HIP gpu-cast   the product library with rm_set_seed_cast(GPU) (saturating (uint) casts, as
+                   gfx950's v_cvt_u32_f32 lowers them in the code objects above)
+    oracle         oracle/rm_restate.c in both cast modes (the checker of every other test)
+
+against each of the three reference builds, over all pixels and over the pixels that are STABLE
+(the three reference builds agree among themselves within 1e-4: the others flip a hit/miss
+decision under legal re-rounding, SURVEY F8, so no implementation can match all builds there).
+
+Usage (GPU box):  python tools/pin_gfx950.py [--quick]   -> gpurun_out/pin_gfx950.txt
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def rel(a, b):
+    a = a.reshape(-1, 4)[:, :3].astype(np.float64)
+    b = b.reshape(-1, 4)[:, :3].astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        r = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+    r[np.isnan(a) | np.isnan(b)] = np.inf
+    r[(np.isnan(a) & np.isnan(b))] = 0.0
+    return r.max(axis=1)
+
+
+def line(name, r, stable):
+    def part(x):
+        if x.size == 0:
+            return "   (none)"
+        q = np.percentile(x, [50, 99, 99.9])
+        return (f"within 1e-4: {100.0 * (x <= 1e-4).mean():8.4f} %  bit-equal-ish(<=1e-7): "
+                f"{100.0 * (x <= 1e-7).mean():7.3f} %  max {x.max():.2e}  p50 {q[0]:.1e} p99 {q[1]:.1e} p99.9 {q[2]:.1e}")
+    return f"    {name:<34} all: {part(r)}\n    {'':<34} stable: {part(r[stable])}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="C1 and a 320x180x2 cut of the C2 geometry only")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pin_gfx950.txt"))
+    args = ap.parse_args()
+
+    import oracle
+    import scenes
+    from raymarchcl_amd import _native
+
+    assert oracle.have_gfx950_ref("fast"), "run `make -C oracle ref_gfx950 runner` in the build container first"
+    cases = [
+        ("BASELINE config 1: 64^3 gyroid 256x256 1 spp :orange-stripes",
+         dict(scenes.SCENES["c1_orange"], w=256, h=256)),
+        ("64^3 gyroid 256x192 3 spp :metal (3 bounces)", dict(scenes.SCENES["metal_3spp"], w=256, h=192)),
+        ("64^3 blobs 256x192 2 spp :metal2 fov 115", dict(scenes.SCENES["metal2_fov115"], vol="blobs", w=256, h=192)),
+    ]
+    if args.quick:
+        cases.append(("config-2 geometry: 256^3 gyroid 320x180 2 spp + DOF :orange-stripes",
+                      dict(vol="gyroid", vres=256, w=320, h=180, iter=2, mat="orange-stripes", theta=-45, dist=2.25,
+                           dof=0.025)))
+    else:
+        cases.append(("BASELINE config 2: 256^3 gyroid 1280x720 16 spp + DOF :orange-stripes",
+                      dict(vol="gyroid", vres=256, w=1280, h=720, iter=16, mat="orange-stripes", theta=-45, dist=2.25,
+                           dof=0.025)))
+    out = [__doc__.split("Usage (GPU box)")[0].strip(), ""]
+    summary = []
+    for title, spec in cases:
+        sc = scenes.build(spec)
+        n = sc["n"]
+        ref, ref_ms = {}, {}
+        for b in oracle.GFX950_BUILDS:
+            ref[b], _, ref_ms[b] = oracle.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], n, build=b, tonemap=False)
+        hip = {}
+        with _native.Context(0) as ctx:
+            ctx.set_volume(sc["vox"], sc["vres"])
+            for mode in ("x86", "gpu"):
+                ctx.set_seed_cast(mode)
+                hip[mode], _ = ctx.render_frame(sc["opts"], sc["mc"], n, want_argb=False)
+        cpu = {}
+        t0 = time.time()
+        for mode in ("x86", "gpu"):
+            with oracle.seed_cast(mode):
+                cpu[mode], _ = oracle.render_frame(sc["vox"], sc["opts"], sc["mc"], n, tonemap=False)
+        t_cpu = time.time() - t0
+        stable = (rel(ref["fast"], ref["strict"]) <= 1e-4) & (rel(ref["fast"], ref["default"]) <= 1e-4) & \
+                 (rel(ref["default"], ref["strict"]) <= 1e-4)
+        out.append(f"{title}  ({n} pixels x {sc['iter']} passes)")
+        out.append(f"  reference kernel on this GPU: " + ", ".join(f"{b} {ref_ms[b]:.1f} ms" for b in ref) +
+                   f" (all passes, device time);  oracle on the host cores: {t_cpu / 2:.1f} s per frame")
+        out.append(f"  stable pixels (the three reference builds agree within 1e-4): {100.0 * stable.mean():.4f} %")
+        for m in ("x86", "gpu"):
+            same = np.array_equal(hip[m].view(np.uint32), cpu[m].view(np.uint32))
+            out.append(f"  HIP {m}-cast == oracle {m}-cast bit for bit: {same}")
+        for b in oracle.GFX950_BUILDS:
+            out.append(f"  against the `{b}` reference build:")
+            for m in ("gpu", "x86"):
+                r = rel(hip[m], ref[b])
+                out.append(line(f"HIP {m}-cast", r, stable))
+                if b == "fast":
+                    summary.append((title.split(":")[0], m, 100.0 * (r <= 1e-4).mean(), 100.0 * (r[stable] <= 1e-4).mean()))
+            out.append(line("oracle gpu-cast", rel(cpu["gpu"], ref[b]), stable))
+            for b2 in oracle.GFX950_BUILDS:
+                if b2 > b:
+                    out.append(line(f"`{b2}` reference build", rel(ref[b2], ref[b]), stable))
+        out.append("")
+        print("\n".join(out[-40:]), flush=True)
+    out.append("Summary -- HIP path against the reference's own build options (`fast`), fraction of pixels within 1e-4:")
+    for t, m, a, s in summary:
+        out.append(f"  {t:<22} HIP {m}-cast: {a:8.4f} % of all pixels, {s:8.4f} % of the stable pixels")
+    text = "\n".join(out)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        f.write(text + "\n")
+    print(text.split("Summary")[1])
+
+
+if __name__ == "__main__":
+    main()
