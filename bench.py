@@ -137,6 +137,11 @@ def main():
                     help="ranks: one process per GPU, torch.distributed (RCCL) gather of the tile accumulators; "
                          "library: ONE process, the frame tiled over N devices inside the C library "
                          "(rm_create_multi: peer copies over xGMI, no RCCL) -- what a JNI caller gets")
+    ap.add_argument("--contract", default="cpu", choices=["cpu", "gfx950"],
+                    help="arithmetic contract of the kernels (include/raymarch_hip.h rm_set_contract): cpu = the "
+                         "results of an OpenCL CPU device (checked against the CPU oracle), gfx950 = the results of "
+                         "the reference kernel built by ROCm's OpenCL compiler for this GPU (checked against that "
+                         "build on the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
@@ -188,7 +193,8 @@ def main():
     vox, vres, opts, mc = build_inputs(wl)
     n, width, spp = wl["w"] * wl["h"], wl["w"], wl["spp"]
     fr = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev,
-                                want_pixels=True, want_argb=True, frames_in_flight=args.frames_in_flight)
+                                want_pixels=True, want_argb=True, frames_in_flight=args.frames_in_flight,
+                                contract=args.contract)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -261,6 +267,8 @@ def main():
             "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]],
                        "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + ((", gloo gather through the host (BENCH_ONE_DEVICE rehearsal: all ranks on one GPU)" if rehearsal
                                      else ", RCCL gather to rank 0") if world > 1 else ""),
+                       "contract": args.contract + (" (OpenCL CPU device semantics; bit-exact vs the CPU oracle)" if args.contract == "cpu"
+                                                    else " (ROCm OpenCL on this GPU; bit-exact vs the reference kernel built for gfx950)"),
                        "frames_in_flight": len(fr.slots),
                        "overlap": ("none: frames are strictly serial" if len(fr.slots) == 1 else
                                    f"ms_per_step is the frame period with {len(fr.slots)} successive frames in flight "
@@ -350,6 +358,7 @@ def library_bench(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     ctx = _native.Context(ids if len(ids) > 1 else 0)
+    ctx.set_contract(args.contract)
     ctx.set_volume(vox, vres)  # replicated to every device of the context
     d_opts = torch.frombuffer(bytearray(opts), dtype=torch.uint8).to(dev)
     d_mc = torch.from_numpy(np.ascontiguousarray(mc, dtype=np.float32).reshape(-1)).to(dev)

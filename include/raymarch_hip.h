@@ -92,6 +92,22 @@ int rm_synchronize(rm_ctx* ctx);
 #define RM_SEED_CAST_X86 0
 #define RM_SEED_CAST_GPU 1
 int rm_set_seed_cast(rm_ctx* ctx, int mode);
+/* The arithmetic contract: WHICH OpenCL device's results the kernels reproduce.  The reference
+ * source leaves the value of its 21 math built-ins (mad, mix, dot, normalize, length, min, max,
+ * clamp, exp, exp2, pow, ...) and of its (int)/(uint) casts to the device it is built for.
+ *   RM_CONTRACT_CPU_DEVICE (default): an OpenCL CPU device on x86-64 -- built-ins as the OpenCL
+ *     1.2 specification defines them operation by operation, x86-64 cast lowering (seed casts per
+ *     rm_set_seed_cast).  Checked bit for bit against the CPU oracle (oracle/).
+ *   RM_CONTRACT_GFX950: this GPU -- the built-ins ARE ROCm's OpenCL built-in library (opencl.bc /
+ *     ocml, linked into the kernels by the symbols the reference kernel links against), casts as
+ *     gfx950 lowers them.  Checked bit for bit, on the GPU, against the unmodified renderer.cl
+ *     built by ROCm's OpenCL compiler for gfx950 with -ffp-contract=off and correctly rounded
+ *     divide/sqrt (oracle/_ref/renderer_gfx950_strict.hsaco, tests/test_gpu_device_contract.py).
+ * Applies to every later render / tonemap / resolve call of the context (all its devices); the
+ * quality mode (rm_render_sdf_frame) and the counting variant always use the first. */
+#define RM_CONTRACT_CPU_DEVICE 0
+#define RM_CONTRACT_GFX950 1
+int rm_set_contract(rm_ctx* ctx, int contract);
 
 /* v-buf: vio/load-volume wraps the bytes into a read-only buffer that the
  * pipeline's first step writes to the device (io.clj:29-33, core.clj:81,146).

@@ -18,8 +18,20 @@ LIB_PATH = os.path.join(HERE, os.path.basename(os.environ.get("RAYMARCH_LIB", "l
 SOURCES = ["rm_kernels.hip", "rm_accel.hip", "rm_volgen.hip", "rm_api.hip", "rm_host.cpp"]
 # -fno-slp-vectorize: packed f32 VALU (v_pk_add_f32 ...) buys nothing on this chip and its
 # even-aligned register pairs cost moves and spills in a 64-VGPR kernel (measured -5 % frame time)
+# Device libraries: hipcc's own set (spelled out because --hip-device-lib replaces it) PLUS opencl.bc,
+# ROCm's OpenCL built-in library: the RM_CONTRACT_GFX950 kernels call the very functions the
+# reference kernel links against when ROCm's OpenCL compiler builds it for this chip (csrc/rm_math.hpp)
+DEVICE_LIBS = ["opencl.bc", "ocml.bc", "ockl.bc", "oclc_daz_opt_off.bc", "oclc_unsafe_math_off.bc",
+               "oclc_finite_only_off.bc", "oclc_correctly_rounded_sqrt_on.bc", "oclc_wavefrontsize64_on.bc",
+               "oclc_isa_version_950.bc", "oclc_abi_version_600.bc"]
+# -disable-machine-sink / -disable-machine-licm: with these two machine-level code motion passes on,
+# the greedy VGPR allocator of this compiler (ROCm 7.2 clang 22) produces instantiations of the frame
+# kernel that render wrong pixels (shadow results of the wave-shared phases go missing) depending on
+# the register budget -- reproduced, bisected and described in DESIGN.md section 4c
+# (tools/repro_gpucast_fault.sh).  Cost of switching them off: 0-4 % of the frame time.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared"]
+               "-shared", "-mllvm", "-disable-machine-sink", "-mllvm", "-disable-machine-licm",
+               "--hip-device-lib-path=/opt/rocm/amdgcn/bitcode"] + ["--hip-device-lib=" + b for b in DEVICE_LIBS]
 
 OPTS_BYTES = 544
 TABLE_FLOATS = 0x4000 * 4
@@ -27,7 +39,7 @@ TABLE_FLOATS = 0x4000 * 4
 # every symbol include/raymarch_hip.h declares
 EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_create_multi", "rm_num_devices",
-    "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_set_contract", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
     "rm_invalidate_volume", "rm_share_volume", "rm_frame_device_full", "rm_last_table_build_ms",
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
@@ -120,6 +132,7 @@ def lib():
     L.rm_set_stream.argtypes = [_vp, _vp]
     L.rm_synchronize.argtypes = [_vp]
     L.rm_set_seed_cast.argtypes = [_vp, _i]
+    L.rm_set_contract.argtypes = [_vp, _i]
     L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
@@ -262,6 +275,12 @@ class Context:
 
     def synchronize(self):
         check(lib().rm_synchronize(self._h))
+
+    def set_contract(self, contract):
+        """"cpu" (default): the results of an OpenCL CPU device on x86-64 (checked against the CPU
+        oracle); "gfx950": the results of the reference kernel built by ROCm's OpenCL compiler for
+        this GPU (include/raymarch_hip.h rm_set_contract)."""
+        check(lib().rm_set_contract(self._h, {"cpu": 0, "gfx950": 1}[contract]))
 
     def set_seed_cast(self, mode):
         """"x86" (default): the undefined (uint) casts of the seed expressions as an OpenCL CPU

@@ -101,6 +101,7 @@ struct rm_ctx {
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
+  int contract = 0;          // rm_set_contract: RM_CONTRACT_CPU_DEVICE (default) / RM_CONTRACT_GFX950
   // records validated by rm_check_device_opts
   std::vector<RmOpts> dev_recs;
   std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
@@ -261,7 +262,8 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   if (rc) return rc;
   HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
-                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt, c->seed_cast));
+                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt, c->seed_cast,
+                                  c->contract == RM_CONTRACT_GFX950 && !counters));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
   rm_counters got{};
   if (counters)
@@ -317,7 +319,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.xcd_rows = c->xcd_rows;
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
-    f.seed_cast_gpu = c->seed_cast;
+    f.arith = (c->contract == RM_CONTRACT_GFX950 && !sdf_frame) ? 2 : (c->seed_cast ? 1 : 0);
     HIP_TRY(rmk::launch_render_frame(c->stream, f));
     launches++;
     i0 = i1;
@@ -494,6 +496,15 @@ int rm_set_seed_cast(rm_ctx* c, int mode) {
   if (mode != RM_SEED_CAST_X86 && mode != RM_SEED_CAST_GPU) return fail(RM_EINVAL, "unknown seed cast mode %d", mode);
   c->seed_cast = mode;
   for (rm_ctx* p : c->peers) p->seed_cast = mode;
+  return RM_OK;
+}
+
+int rm_set_contract(rm_ctx* c, int contract) {
+  if (!c) return fail(RM_EINVAL, "rm_ctx is NULL");
+  if (contract != RM_CONTRACT_CPU_DEVICE && contract != RM_CONTRACT_GFX950)
+    return fail(RM_EINVAL, "unknown arithmetic contract %d", contract);
+  c->contract = contract;
+  for (rm_ctx* p : c->peers) p->contract = contract;
   return RM_OK;
 }
 
@@ -735,7 +746,7 @@ int rm_tonemap_image(rm_ctx* c, const float* pixels, const void* opts544, uint32
   HIP_TRY(hipMemcpyAsync(c->pix_buf.p, pixels, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(rmk::launch_tonemap(c->stream, static_cast<const float*>(c->pix_buf.p),
                               static_cast<const RmOpts*>(c->opts_buf.p),
-                              static_cast<uint32_t*>(c->argb_buf.p), n));
+                              static_cast<uint32_t*>(c->argb_buf.p), n, c->contract == RM_CONTRACT_GFX950));
   HIP_TRY(hipMemcpyAsync(argb, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
@@ -803,7 +814,7 @@ static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc
   HIP_TRY(hipSetDevice(c->device));
   for (rm_ctx* p : c->peers) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_done, 0));
   HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp, d_opts, d_pixels,
-                              d_argb, n));
+                              d_argb, n, c->contract == RM_CONTRACT_GFX950 && !sdf));
   HIP_TRY(hipEventRecord(c->ev_resolved, c->stream));
   c->resolved_once = true;
   return RM_OK;
@@ -1010,7 +1021,7 @@ int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void
   if (parts < 1 || n <= 0 || width <= 0) return fail(RM_EINVAL, "parts = %d, n = %d, width = %d", parts, n, width);
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(width, n), parts);
   HIP_TRY(rmk::launch_resolve(c->stream, d_tiles_all, parts, tpp, static_cast<const RmOpts*>(d_opts),
-                              d_pixels, d_argb, n));
+                              d_pixels, d_argb, n, c->contract == RM_CONTRACT_GFX950));
   return RM_OK;
 }
 

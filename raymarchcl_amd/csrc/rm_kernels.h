@@ -33,7 +33,7 @@ hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, i
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters, int seed_cast_gpu = 0);
+                              Counters* d_counters, int seed_cast_gpu = 0, bool device_arith = false);
 // One launch of the frame kernel (rm_kernels.hip render_frame_kernel): `passes` consecutive
 // RenderImage passes over partition (tile_first, tile_stride) of the image, blended in order
 // into `acc`.  pp_log2 > 0: a wavefront holds 2^pp_log2 passes of 64/2^pp_log2 pixels -- only
@@ -50,15 +50,18 @@ struct FrameLaunch {
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int min_waves = 7, pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
-  int seed_cast_gpu = 0;           // rm_set_seed_cast
+  // arithmetic contract (rm_math.hpp): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
+  // the seed casts (rm_set_seed_cast), 2 = ROCm's OpenCL library on this GPU (rm_set_contract)
+  int arith = 0;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
 int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
-                          const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n);
+                          const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n,
+                          bool device_arith = false);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
-                          uint32_t* d_argb, int n);
+                          uint32_t* d_argb, int n, bool device_arith = false);
 // surf32 of a resident volume for hit threshold `iso` (rm_accel.hip) and -- when d_dist is not
 // null -- dist8 alone by separable passes (d_tmp: scratch of the volume's size)
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,

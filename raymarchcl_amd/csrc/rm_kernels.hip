@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <type_traits>
 
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
@@ -63,7 +64,9 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
 // contiguous 1 KiB store per wave) instead of at the work-item id; used by the
 // device-resident pipeline and the multi-GPU partition, un-permuted by
 // resolve_kernel.
-template <bool COUNT, bool TILE_MAJOR, bool ACCEL, bool BRICK = false>
+// DEVICE: the arithmetic contract -- false: OpenCL CPU device (seed-cast lowering chosen at run
+// time), true: ROCm's OpenCL library on this GPU (rm_math.hpp)
+template <bool COUNT, bool TILE_MAJOR, bool ACCEL, bool BRICK = false, bool DEVICE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
@@ -79,15 +82,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
   rmk::Scene sc{vox, mc, opts, dist8, surf32, oct_stride};
   sc.seed_cast_gpu = seed_cast_gpu;
-  rmk::Tracer<COUNT, ACCEL, false, BRICK> tr(sc);
+  using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<2>>::type;
+  rmk::Tracer<COUNT, ACCEL, false, BRICK, M> tr(sc);
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
     const float fb = opts->frameBlend;
     const long long at = TILE_MAJOR ? slot * 64 + lane : (long long)id;
     const float4 p = pixels[at];
     // mix(p, col, frameBlend): renderer.cl:492
-    pixels[at] = make_float4(p.x + (col.x - p.x) * fb, p.y + (col.y - p.y) * fb,
-                             p.z + (col.z - p.z) * fb, 1.0f);
+    pixels[at] = make_float4(M::mix(p.x, col.x, fb), M::mix(p.y, col.y, fb), M::mix(p.z, col.z, fb), 1.0f);
   }
   if (COUNT) {
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(counters);
@@ -134,13 +137,14 @@ struct FrameArgs {
   int row_major;                       // acc is indexed by work-item id instead of slot*64 + pixel
 };
 
+template <class M>
 __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, float g) {
   const float c[3] = {px, py, pz};
   uint32_t ch[3];
   for (int k = 0; k < 3; k++) {
     const float t = c[k] / (g + c[k]);
     const float v = t * t * 255.0f;
-    ch[k] = (uint32_t)rmd::f2i(rmd::clamp_cl(v, 0.0f, 255.0f));
+    ch[k] = (uint32_t)M::to_int(M::clamp(v, 0.0f, 255.0f));
   }
   return 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
 }
@@ -150,9 +154,12 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 #ifndef RM_PERSISTENT
 #define RM_PERSISTENT 0  // A/B: a resident grid whose wavefronts stride over the frame's blocks
 #endif
-template <bool ACCEL, bool SDFM, bool MULTI, bool BRICK, bool GPUCAST>
+// ARITH: 0 = OpenCL CPU device arithmetic and casts, 1 = the same with the GPU lowering of the seed
+// casts, 2 = ROCm's OpenCL library on this GPU (rm_math.hpp)
+template <bool ACCEL, bool SDFM, bool MULTI, bool BRICK, int ARITH>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
-  using Tr = rmk::Tracer<false, ACCEL, SDFM, BRICK, GPUCAST ? 1 : 0>;
+  using M = typename std::conditional<ARITH == 2, rmk::MathOcl, rmk::MathX86<(ARITH == 1 ? 1 : 0)>>::type;
+  using Tr = rmk::Tracer<false, ACCEL, SDFM, BRICK, M>;
   const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
@@ -218,17 +225,17 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
         const int cnt = min(pp, a.passes - c0);  // uniform
         for (int k = 0; k < cnt; k++) {
           const float fb = a.opts_all[c0 + k].frameBlend;
-          px = px + (blend_lds[lane + k] - px) * fb;
-          py = py + (blend_lds[64 + lane + k] - py) * fb;
-          pz = pz + (blend_lds[128 + lane + k] - pz) * fb;
+          px = M::mix(px, blend_lds[lane + k], fb);
+          py = M::mix(py, blend_lds[64 + lane + k], fb);
+          pz = M::mix(pz, blend_lds[128 + lane + k], fb);
         }
       }
       __syncthreads();
     } else {
       const float fb = opts->frameBlend;
-      px = px + (col.x - px) * fb;
-      py = py + (col.y - py) * fb;
-      pz = pz + (col.z - pz) * fb;
+      px = M::mix(px, col.x, fb);
+      py = M::mix(py, col.y, fb);
+      pz = M::mix(pz, col.z, fb);
     }
 #ifdef RM_PHASE_CLOCK
     for (int k = 0; k < 5; k++) ws_acc[32 + k] += tr.ws_clk[k];
@@ -262,7 +269,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   }
   if (first) {
     a.acc[at] = make_float4(px, py, pz, 1.0f);
-    if (a.argb) a.argb[id] = tonemap_argb(px, py, pz, a.opts0->gamma);
+    if (a.argb) a.argb[id] = tonemap_argb<M>(px, py, pz, a.opts0->gamma);
   }
 #if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
   for (int k = 0; k < 64; k++)
@@ -270,21 +277,22 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
 #endif
 }
 
-template <bool ACCEL, int MINW, bool SDFM, bool MULTI, bool BRICK = false, bool GPUCAST = false>
+template <bool ACCEL, int MINW, bool SDFM, bool MULTI, bool BRICK = false, int ARITH = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
   __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
 #if RM_PERSISTENT
   // (stride = grid size, a multiple of 8: a wavefront stays on the tile rows of its XCD)
   for (long long b = blockIdx.x; b < a.total_blocks; b += gridDim.x) {
-    frame_block<ACCEL, SDFM, MULTI, BRICK, GPUCAST>(a, b, wave_lds);
+    frame_block<ACCEL, SDFM, MULTI, BRICK, ARITH>(a, b, wave_lds);
     __syncthreads();
   }
 #else
-  frame_block<ACCEL, SDFM, MULTI, BRICK, GPUCAST>(a, blockIdx.x, wave_lds);
+  frame_block<ACCEL, SDFM, MULTI, BRICK, ARITH>(a, blockIdx.x, wave_lds);
 #endif
 }
 
+template <bool DEVICE>
 __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ pixels,
                                                       const RmOpts* __restrict__ opts,
                                                       uint32_t* __restrict__ argb, int n) {
@@ -292,13 +300,15 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
   for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n;
        id += (long long)gridDim.x * blockDim.x) {
     const float4 p = pixels[id];
-    argb[id] = tonemap_argb(p.x, p.y, p.z, g);
+    using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<0>>::type;
+    argb[id] = tonemap_argb<M>(p.x, p.y, p.z, g);
   }
 }
 
 // Tile-major accumulators of `parts` interleaved partitions (partition r owns
 // tiles r, r+parts, ...; each partition's buffer holds tiles_per_part tiles of
 // 64 float4) -> row-major float4 pixels and/or tonemapped ARGB.
+template <bool DEVICE>
 __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__ tiles, int parts,
                                                       int tiles_per_part,
                                                       const RmOpts* __restrict__ opts,
@@ -315,7 +325,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
     const long long at = ((long long)(tile % parts) * tiles_per_part + tile / parts) * 64 + lane;
     const float4 p = tiles[at];
     if (pixels) pixels[id] = p;
-    if (argb) argb[id] = tonemap_argb(p.x, p.y, p.z, g);
+    using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<0>>::type;
+    if (argb) argb[id] = tonemap_argb<M>(p.x, p.y, p.z, g);
   }
 }
 
@@ -354,8 +365,8 @@ __global__ void filter_check_kernel(const float* __restrict__ rays, const RmOpts
   rmk::Scene sc{nullptr, nullptr, opts, nullptr, nullptr};
   rmk::Tracer<false, true> tr(sc);
   const auto flt = tr.make_filter(ro, rd);
-  const rmk::v3 rpos = rmk::mads(rd, t, ro);  // the position march() hands to the estimate
-  const float t_in = rmk::box_entry_of(*opts, rpos, rd);
+  const rmk::v3 rpos = rmk::muladd(rd, t, ro);  // the position march() hands to the estimate
+  const float t_in = rmk::box_entry_of<rmk::MathX86<0>>(*opts, rpos, rd);
   const RmOpts& o = *opts;
   const float m = 1e-4f;  // scene_distance's RM_INSIDE_TEST margin
   const bool inside = (rpos.x - o.voxelBoundsMin[0] > m) & (o.voxelBoundsMax[0] - rpos.x > m) &
@@ -452,7 +463,7 @@ void dump_work_stats() {
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters, int seed_cast_gpu) {
+                              Counters* d_counters, int seed_cast_gpu, bool device_arith) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const long long my_tiles =
@@ -463,16 +474,23 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   float4* px4 = reinterpret_cast<float4*>(pixels);
   const dim3 grid(blocks), block(64 * kWavesPerBlock);
   const bool acc = accel.dist && accel.surf;
-#define RM_LAUNCH(C, T, A, B)                                                                      \
-  render_pass_kernel<C, T, A, B><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, \
-                                                         px4, n, id0, id1, tile_first, tile_stride, \
-                                                         d_counters, accel.oct_stride, seed_cast_gpu)
-  if (d_counters) RM_LAUNCH(true, false, false, false);
+#define RM_LAUNCH(C, T, A, B)                                                                                     \
+  do {                                                                                                            \
+    if (device_arith)                                                                                             \
+      render_pass_kernel<C, T, A, B, true><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, px4, \
+                                                                   n, id0, id1, tile_first, tile_stride,          \
+                                                                   d_counters, accel.oct_stride, seed_cast_gpu);  \
+    else                                                                                                          \
+      render_pass_kernel<C, T, A, B, false><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts,     \
+                                                                    px4, n, id0, id1, tile_first, tile_stride,    \
+                                                                    d_counters, accel.oct_stride, seed_cast_gpu); \
+  } while (0)
+  if (d_counters) { RM_LAUNCH(true, false, false, false); }
   else if (acc && accel.bricked) { if (tile_major) RM_LAUNCH(false, true, true, true); else RM_LAUNCH(false, false, true, true); }
-  else if (tile_major && acc) RM_LAUNCH(false, true, true, false);
-  else if (tile_major) RM_LAUNCH(false, true, false, false);
-  else if (acc) RM_LAUNCH(false, false, true, false);
-  else RM_LAUNCH(false, false, false, false);
+  else if (tile_major && acc) { RM_LAUNCH(false, true, true, false); }
+  else if (tile_major) { RM_LAUNCH(false, true, false, false); }
+  else if (acc) { RM_LAUNCH(false, false, true, false); }
+  else { RM_LAUNCH(false, false, false, false); }
 #undef RM_LAUNCH
   return hipGetLastError();
 }
@@ -534,54 +552,64 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
 #endif
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   const bool multi = f.passes > (1 << pp_log2);
+#ifndef RM_GPUCAST_MINW
+#define RM_GPUCAST_MINW 7
+#endif
 #define RM_FRAME(A, W, S, B, G)                                                     \
   do {                                                                              \
     if (multi) render_frame_kernel<A, W, S, true, B, G><<<grid, block, 0, st>>>(a);  \
     else render_frame_kernel<A, W, S, false, B, G><<<grid, block, 0, st>>>(a);       \
   } while (0)
-  const bool gpucast = f.seed_cast_gpu != 0;
-  if (f.sdf) {
-    if (gpucast) RM_FRAME(false, 4, true, false, true); else RM_FRAME(false, 4, true, false, false);
+#define RM_FRAME_ARITH(A, W, S, B)                  \
+  do {                                              \
+    if (f.arith == 2) RM_FRAME(A, W, S, B, 2);      \
+    else if (f.arith == 1) RM_FRAME(A, W, S, B, 1); \
+    else RM_FRAME(A, W, S, B, 0);                   \
+  } while (0)
+  if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
+    if (f.arith == 1) RM_FRAME(false, 4, true, false, 1); else RM_FRAME(false, 4, true, false, 0);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
     // (volumes whose tables exceed the caches: one register budget, the default)
-    if (gpucast) RM_FRAME(true, 7, false, true, true); else RM_FRAME(true, 7, false, true, false);
+    RM_FRAME_ARITH(true, 7, false, true);
   } else if (f.accel.dist && f.accel.surf) {
-    if (gpucast) {  // (one register budget for the GPU-cast mode)
-#ifndef RM_GPUCAST_MINW
-#define RM_GPUCAST_MINW 7
-#endif
-      RM_FRAME(true, RM_GPUCAST_MINW, false, false, true);
+    if (f.arith != 0) {  // (one register budget for the other contracts)
+      RM_FRAME_ARITH(true, RM_GPUCAST_MINW, false, false);
     } else switch (f.min_waves) {
-      case 4: RM_FRAME(true, 4, false, false, false); break;
-      case 5: RM_FRAME(true, 5, false, false, false); break;
-      case 6: RM_FRAME(true, 6, false, false, false); break;
-      case 8: RM_FRAME(true, 8, false, false, false); break;
-      default: RM_FRAME(true, 7, false, false, false); break;
+      case 4: RM_FRAME(true, 4, false, false, 0); break;
+      case 5: RM_FRAME(true, 5, false, false, 0); break;
+      case 6: RM_FRAME(true, 6, false, false, 0); break;
+      case 8: RM_FRAME(true, 8, false, false, 0); break;
+      default: RM_FRAME(true, 7, false, false, 0); break;
     }
   } else {
-    if (gpucast) RM_FRAME(false, 3, false, false, true); else RM_FRAME(false, 3, false, false, false);
+    RM_FRAME_ARITH(false, 3, false, false);
   }
+#undef RM_FRAME_ARITH
 #undef RM_FRAME
   return hipGetLastError();
 }
 
 hipError_t launch_tonemap(hipStream_t st, const float* pixels, const RmOpts* d_opts, uint32_t* argb,
-                          int n) {
+                          int n, bool device_arith) {
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  tonemap_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
+  if (device_arith) tonemap_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
+  else tonemap_kernel<false><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
   return hipGetLastError();
 }
 
 hipError_t launch_resolve(hipStream_t st, const float* tiles, int parts, int tiles_per_part,
-                          const RmOpts* d_opts0, float* pixels, uint32_t* argb, int n) {
+                          const RmOpts* d_opts0, float* pixels, uint32_t* argb, int n, bool device_arith) {
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  resolve_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts,
-                                         tiles_per_part, d_opts0, reinterpret_cast<float4*>(pixels),
-                                         argb, n);
+  if (device_arith)
+    resolve_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part, d_opts0,
+                                                 reinterpret_cast<float4*>(pixels), argb, n);
+  else
+    resolve_kernel<false><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part, d_opts0,
+                                                  reinterpret_cast<float4*>(pixels), argb, n);
   return hipGetLastError();
 }
 

@@ -2,41 +2,17 @@
 // behaviour of the reference device functions
 // (/root/reference/resources/renderer.cl:142-476; the function each routine
 // replaces is cited next to it).  Scalar float32 throughout, every expression
-// in the reference's evaluation order, no FMA contraction (see rm_detmath.hpp).
+// in the reference's evaluation order, no FMA contraction; the value of the reference's math
+// built-ins comes from the arithmetic contract M (rm_math.hpp: OpenCL CPU device / this GPU).
 //
 // One lane owns one sample from camera ray to final colour (shade()); in the frame kernel
 // the AO probes and shadow rays of a wavefront's hits are traced by all its lanes
 // (shade_wave()).  rm_kernels.hip wraps both in the kernels.
 #pragma once
-#include "rm_detmath.hpp"
+#include "rm_math.hpp"
 #include "rm_opts.h"
 
 namespace rmk {
-
-struct v3 { float x, y, z; };
-RM_DEV v3 V(float x, float y, float z) { return v3{x, y, z}; }
-RM_DEV v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
-RM_DEV v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
-RM_DEV v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
-RM_DEV v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
-RM_DEV v3 operator-(v3 a) { return V(-a.x, -a.y, -a.z); }
-RM_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-RM_DEV v3 cross(v3 a, v3 b) {
-  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-// a*s + c, two roundings per component (the reference's mad() on a CPU device)
-RM_DEV v3 mads(v3 a, float s, v3 c) { return V(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z); }
-RM_DEV v3 madv(v3 a, v3 b, v3 c) { return V(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z); }
-RM_DEV v3 mixs(v3 a, v3 b, float t) {
-  return V(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t);
-}
-RM_DEV v3 normalize(v3 v) {
-  if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
-  const float s = 1.0f / rmd::sqrt_rn(dot(v, v));
-  return v * s;
-}
-RM_DEV float length(v3 v) { return rmd::sqrt_rn(dot(v, v)); }
-RM_DEV v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
 
 // Optional device-side event counters (algorithmic bytes for the roofline).
 struct Counters {
@@ -83,15 +59,16 @@ RM_DEV Material material_of(const RmOpts& o, int id, bool* oob = nullptr) {
   return m;
 }
 // slab test: renderer.cl:153-161
+template <class M>
 RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
   const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
               loz = (o.voxelBoundsMin[2] - p.z) / d.z;
   const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
               hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
-  const float nx = rmd::fmin_cl(hix, lox), ny = rmd::fmin_cl(hiy, loy), nz = rmd::fmin_cl(hiz, loz);
-  const float a = rmd::fmax_cl(rmd::fmax_cl(nx, 0.0f), rmd::fmax_cl(ny, nz));
-  const float fx = rmd::fmax_cl(hix, lox), fy = rmd::fmax_cl(hiy, loy), fz = rmd::fmax_cl(hiz, loz);
-  const float b = rmd::fmin_cl(fx, rmd::fmin_cl(fy, fz));
+  const float nx = M::fmin(hix, lox), ny = M::fmin(hiy, loy), nz = M::fmin(hiz, loz);
+  const float a = M::fmax(M::fmax(nx, 0.0f), M::fmax(ny, nz));
+  const float fx = M::fmax(hix, lox), fy = M::fmax(hiy, loy), fz = M::fmax(hiz, loz);
+  const float b = M::fmin(fx, M::fmin(fy, fz));
   return b > a ? a : -1.0f;
 }
 RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {  // 0 <= q < res per axis
@@ -99,39 +76,44 @@ RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {  // 0 <= q < r
          ((unsigned)qx < (unsigned)o.voxelRes[0]);
 }
 // renderer.cl:259-261
+template <class M>
 RM_DEV v3 sky_of(const RmOpts& o, v3 dir) {
-  return mixs(ld3(o.skyColor1), ld3(o.skyColor2), dir.y * 0.5f + 0.5f);
+  return M::mixs(ld3(o.skyColor1), ld3(o.skyColor2), dir.y * 0.5f + 0.5f);
 }
 // renderer.cl:271-273
+template <class M>
 RM_DEV v3 reflect_of(v3 v, v3 n) {
-  const float k = 2.0f * dot(v, n);
+  const float k = 2.0f * M::dot(v, n);
   return v - n * k;
 }
 // renderer.cl:304-311
+template <class M>
 RM_DEV float schlick_of(float r0, float smooth, v3 n, v3 view) {
-  const float d = rmd::clamp_cl(1.0f - dot(n, -view), 0.0f, 1.0f);
+  const float d = M::clamp(1.0f - M::dot(n, -view), 0.0f, 1.0f);
   if (d > 0.0f) {
     const float d2 = d * d;
-    return (1.0f - r0) * (smooth * d2 * d2 * d) + r0;
+    return M::mad(1.0f - r0, smooth * d2 * d2 * d, r0);
   }
   return 0.0f;
 }
 // renderer.cl:317-325
+template <class M>
 RM_DEV float blinn_phong_of(float smooth, v3 raydir, v3 ldir, v3 n) {
-  const float nh = dot(normalize(ldir - raydir), n);
+  const float nh = M::dot(M::normalize(ldir - raydir), n);
   if (nh > 0.0f) {
-    const float sp = rmd::exp2_det(6.0f * smooth + 4.0f);
-    return rmd::pow_det(nh, sp) * (sp + 2.0f) * 0.125f;
+    const float sp = M::exp2(M::mad(6.0f, smooth, 4.0f));
+    return M::pow(nh, sp) * (sp + 2.0f) * 0.125f;
   }
   return 0.0f;
 }
 // decode of a surf32 word (rm_accel.hip) into the hit normal and material code
+template <class M>
 RM_DEV v3 surf_normal(uint32_t w, bool smooth) {
   if (smooth)
-    return normalize(V((float)((int)((w >> 8) & 63u) - 32), (float)((int)((w >> 14) & 63u) - 32),
+    return M::normalize(V((float)((int)((w >> 8) & 63u) - 32), (float)((int)((w >> 14) & 63u) - 32),
                        (float)((int)((w >> 20) & 63u) - 32)));
-  return normalize(V(-(float)((int)((w >> 26) & 3u) - 1), -(float)((int)((w >> 28) & 3u) - 1),
-                     -(float)((int)((w >> 30) & 3u) - 1)));
+  return M::normalize(V(-(float)((int)((w >> 26) & 3u) - 1), -(float)((int)((w >> 28) & 3u) - 1),
+                        -(float)((int)((w >> 30) & 3u) - 1)));
 }
 RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }  // renderer.cl:205-207
 
@@ -153,13 +135,14 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 // (rm_accel.hip), chosen by the host for volumes whose tables exceed the Infinity Cache: a ray's
 // consecutive fetches and the lanes of a wavefront then share lines instead of touching a new
 // 128-byte row segment per fetch.
-template <bool BRICK = false>
+template <class M, bool BRICK = false>
 RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
                      float inv_s, int* cell_out, unsigned long long table_off = 0, unsigned int* dhist = nullptr,
                      const uint8_t* __restrict__ coarse = nullptr, unsigned int coarse_off = 0) {
-  const int qx = rmd::convert_int_sat(p.x * (float)o.voxelRes[0]);
-  const int qy = rmd::convert_int_sat(p.y * (float)o.voxelRes[1]);
-  const int qz = rmd::convert_int_sat(p.z * (float)o.voxelRes[2]);
+  // (M::cell: the bare conversion instruction; scene_distance has applied M::walk_guard)
+  const int qx = M::cell(p.x * (float)o.voxelRes[0]);
+  const int qy = M::cell(p.y * (float)o.voxelRes[1]);
+  const int qz = M::cell(p.z * (float)o.voxelRes[2]);
   if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
   // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
   // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
@@ -243,11 +226,20 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
 #endif
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
 // come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
-// CAST: lowering of the undefined (uint) seed casts -- 0: x86-64 (wrap), 1: GPU (saturate),
-// 2: chosen at run time by Scene::seed_cast_gpu (the single-pass parity kernels; the frame kernel
-// is instantiated per mode so that the flag costs its hot code nothing)
-template <bool COUNT, bool ACCEL = false, bool SDFM = false, bool BRICK = false, int CAST = 2>
+// M: the arithmetic contract (rm_math.hpp) -- MathX86<0> OpenCL CPU device, MathX86<1> the same
+// with the GPU lowering of the seed casts, MathX86<2> cast lowering chosen at run time by
+// Scene::seed_cast_gpu (single-pass parity kernels; the frame kernel is instantiated per mode so
+// that the flag costs its hot code nothing), MathOcl: ROCm's OpenCL library on this GPU
+template <bool COUNT, bool ACCEL = false, bool SDFM = false, bool BRICK = false, class M = MathX86<2>>
 struct Tracer {
+  // the reference's built-ins under the contract (unqualified calls below resolve to these)
+  RM_DEV static float dot(v3 a, v3 b) { return M::dot(a, b); }
+  RM_DEV static v3 cross(v3 a, v3 b) { return M::cross(a, b); }
+  RM_DEV static v3 normalize(v3 a) { return M::normalize(a); }
+  RM_DEV static float length(v3 a) { return M::length(a); }
+  RM_DEV static v3 mads(v3 a, float s, v3 c) { return M::mads(a, s, c); }
+  RM_DEV static v3 madv(v3 a, v3 b, v3 c) { return M::madv(a, b, c); }
+  RM_DEV static v3 mixs(v3 a, v3 b, float t) { return M::mixs(a, b, t); }
   static_assert(!(COUNT && ACCEL), "event counts are defined on the reference algorithm");
   static_assert(!(SDFM && (COUNT || ACCEL)), "the quality mode has no counters and no derived tables");
   const Scene& sc;
@@ -315,11 +307,7 @@ struct Tracer {
 
   // the (uint) cast of a seed expression (renderer.cl:267, 334, 471, 472): undefined outside
   // [0, 2^32); x86-64 lowering by default, GPU lowering on request (uniform branch)
-  RM_DEV uint32_t seed_of(float x) {
-    if (CAST == 0) return rmd::f2u(x);
-    if (CAST == 1) return rmd::f2u_gpu(x);
-    return sc.seed_cast_gpu ? rmd::f2u_gpu(x) : rmd::f2u(x);
-  }
+  RM_DEV uint32_t seed_of(float x) { return M::seed(x, sc.seed_cast_gpu); }
   // scatter table lookup: renderer.cl:142-144
   RM_DEV float4 table(uint32_t seed) {
     if (COUNT) cnt.mc_reads++;
@@ -332,7 +320,7 @@ struct Tracer {
     if (COUNT && oob) cnt.oob_material++;
     return m;
   }
-  RM_DEV float box_entry(v3 p, v3 d) { return box_entry_of(*sc.o, p, d); }
+  RM_DEV float box_entry(v3 p, v3 d) { return box_entry_of<M>(*sc.o, p, d); }
 
   RM_DEV bool in_grid(int qx, int qy, int qz) { return in_grid_of(*sc.o, qx, qy, qz); }
   // binary occupancy: renderer.cl:172-178
@@ -340,7 +328,7 @@ struct Tracer {
     const RmOpts& o = *sc.o;
     if (!in_grid(qx, qy, qz)) return 0.0f;
     if (COUNT) cnt.vox_reads++;
-    return rmd::step_cl((float)o.isoVal, (float)sc.vox[qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx]);
+    return M::step((float)o.isoVal, (float)sc.vox[qz * o.voxelRes[3] + qy * o.voxelRes[0] + qx]);
   }
   // negated central difference: renderer.cl:180-188
   RM_DEV v3 cell_gradient(int qx, int qy, int qz) {
@@ -365,9 +353,9 @@ struct Tracer {
   RM_DEV float sdf_sample(v3 q) {
     const RmOpts& o = *sc.o;
     const int rx = o.voxelRes[0], ry = o.voxelRes[1], rz = o.voxelRes[2];
-    const float ux = rmd::clamp_cl((q.x + o.voxelBounds[0]) * o.invVoxelScale[0] * (float)rx - 0.5f, 0.0f, (float)(rx - 1));
-    const float uy = rmd::clamp_cl((q.y + o.voxelBounds[1]) * o.invVoxelScale[1] * (float)ry - 0.5f, 0.0f, (float)(ry - 1));
-    const float uz = rmd::clamp_cl((q.z + o.voxelBounds[2]) * o.invVoxelScale[2] * (float)rz - 0.5f, 0.0f, (float)(rz - 1));
+    const float ux = M::clamp((q.x + o.voxelBounds[0]) * o.invVoxelScale[0] * (float)rx - 0.5f, 0.0f, (float)(rx - 1));
+    const float uy = M::clamp((q.y + o.voxelBounds[1]) * o.invVoxelScale[1] * (float)ry - 0.5f, 0.0f, (float)(ry - 1));
+    const float uz = M::clamp((q.z + o.voxelBounds[2]) * o.invVoxelScale[2] * (float)rz - 0.5f, 0.0f, (float)(rz - 1));
     int ix = (int)ux, iy = (int)uy, iz = (int)uz;  // u >= 0: truncation = floor
     ix = min(ix, rx - 2); iy = min(iy, ry - 2); iz = min(iz, rz - 2);
     ix = max(ix, 0); iy = max(iy, 0); iz = max(iz, 0);
@@ -388,9 +376,9 @@ struct Tracer {
   // the box is added to the value at the nearest point of the box
   RM_DEV float sdf_volume(v3 p) {
     const RmOpts& o = *sc.o;
-    const v3 q = V(rmd::clamp_cl(p.x, o.voxelBoundsMin[0], o.voxelBoundsMax[0]),
-                   rmd::clamp_cl(p.y, o.voxelBoundsMin[1], o.voxelBoundsMax[1]),
-                   rmd::clamp_cl(p.z, o.voxelBoundsMin[2], o.voxelBoundsMax[2]));
+    const v3 q = V(M::clamp(p.x, o.voxelBoundsMin[0], o.voxelBoundsMax[0]),
+                   M::clamp(p.y, o.voxelBoundsMin[1], o.voxelBoundsMax[1]),
+                   M::clamp(p.z, o.voxelBoundsMin[2], o.voxelBoundsMax[2]));
     return sdf_sample(q) + length(p - q);
   }
   RM_DEV void scene_distance_sdf(v3 rpos, v3 dir, float& dist, float& code, v3& nrm) {
@@ -419,19 +407,19 @@ struct Tracer {
   // penumbra estimate along a light ray: min over the march of k * clearance / distance
   RM_DEV float soft_shadow_sdf(v3 p, v3 ldir, float lmax) {
     const RmOpts& o = *sc.o;
-    const float k = 1.0f / rmd::fmax_cl(o.lightScatter, 0.01f);
+    const float k = 1.0f / M::fmax(o.lightScatter, 0.01f);
     float res = 1.0f;
     float t = 0.0f;
     for (int i = 0; i < o.shadowIter; i++) {
       const v3 q = mads(ldir, t, p);
       const float h = q.y + o.groundY;
-      const float d = rmd::fmin_cl(h < 1e5f ? h : 1e5f, sdf_volume(q));
+      const float d = M::fmin(h < 1e5f ? h : 1e5f, sdf_volume(q));
       if (d <= o.eps * 0.5f) return 0.0f;
-      res = rmd::fmin_cl(res, k * d / (t + o.shadowBias));
-      t += rmd::fmax_cl(d, o.eps);
+      res = M::fmin(res, k * d / (t + o.shadowBias));
+      t += M::fmax(d, o.eps);
       if (t >= lmax) break;
     }
-    return rmd::clamp_cl(res, 0.0f, 1.0f);
+    return M::clamp(res, 0.0f, 1.0f);
   }
 
   // ---- walks that only have to look as far as their result can depend on ----
@@ -523,6 +511,7 @@ struct Tracer {
       if (ACCEL) {
         const bool limited = walk_limit < steps;
         if (limited) steps = walk_limit;
+        M::walk_guard(p, delta, steps);  // (device contract: a NaN operand ends the walk where the library conversion would)
         // cells per sample along the fastest axis, padded: bounds how many samples
         // certainly stay inside the empty neighbourhood dist8 reports
         const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
@@ -561,9 +550,9 @@ struct Tracer {
           RM_WS(ws_steps += (unsigned)steps);
           RM_WS(ws_nf++);
 #ifdef RM_WORK_STATS
-          r = walk_step<BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist, sc.coarse, coarse_off);
+          r = walk_step<M, BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist, sc.coarse, coarse_off);
 #else
-          r = walk_step<BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, nullptr, sc.coarse, coarse_off);
+          r = walk_step<M, BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, nullptr, sc.coarse, coarse_off);
 #endif
           RM_WS(ws_steps -= (unsigned)steps);
 #ifdef RM_WORK_STATS
@@ -584,7 +573,7 @@ struct Tracer {
         if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
-          nrm = surf_normal(w, smooth);
+          nrm = surf_normal<M>(w, smooth);
           const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
           const float d = length(rpos - hit) - o.voxelSize;
           if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }
@@ -593,9 +582,8 @@ struct Tracer {
         RM_CLK_ADD(7, ck_w1, ck_w2);
       } else
       while (--steps >= 0) {
-        const int qx = rmd::convert_int_sat(p.x * frx);
-        const int qy = rmd::convert_int_sat(p.y * fry);
-        const int qz = rmd::convert_int_sat(p.z * frz);
+        int qx, qy, qz;
+        M::cell3(p.x * frx, p.y * fry, p.z * frz, qx, qy, qz);
         if (COUNT) cnt.march_steps++;
         if (!in_grid(qx, qy, qz)) break;
         if (COUNT) cnt.vox_reads++;
@@ -768,7 +756,7 @@ struct Tracer {
       // is a filtered one or finds its hit close by)
       if (ACCEL && RM_LAZY_NORMAL && !distance_only) limit = walk_limit_from(g, spu);
       cut_last = false;
-      scene_distance(mads(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
+      scene_distance(muladd(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
                      &cut_last);
       last_kind = 1;
 #ifdef RM_WORK_STATS
@@ -781,7 +769,7 @@ struct Tracer {
       dist += sd;
     }
     if (maxSteps != turns0) {  // at least one turn: renderer.cl:244-246 values of the last one
-      r.pos = mads(rdir, last_t, ro);
+      r.pos = muladd(rdir, last_t, ro);
       if (ACCEL && RM_LAZY_NORMAL && !distance_only && last_kind == 1 && cut_last) {
         RM_WS(ws_redo++);
         float sd2, sc2;
@@ -792,10 +780,10 @@ struct Tracer {
         scode = h < 1e5f ? h : -1.0f;
         r.normal = (h < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;
       }
-      r.objectID = rmd::f2i(scode);
+      r.objectID = M::to_int(scode);
     }
     if (dist >= maxDist) {
-      r.pos = mads(rdir, dist, ro);
+      r.pos = muladd(rdir, dist, ro);
       r.objectID = -1;
       dist = 1000.0f;
     }
@@ -803,7 +791,7 @@ struct Tracer {
   }
 
 
-  RM_DEV v3 sky(v3 dir) { return sky_of(*sc.o, dir); }
+  RM_DEV v3 sky(v3 dir) { return sky_of<M>(*sc.o, dir); }
 
   struct Sample { v3 eye; v3 mcNormal; float px, py; float time; };
 
@@ -814,17 +802,17 @@ struct Tracer {
     const float4 r = table(seed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
-  RM_DEV v3 reflect(v3 v, v3 n) { return reflect_of(v, n); }
+  RM_DEV v3 reflect(v3 v, v3 n) { return reflect_of<M>(v, n); }
   // fog + flares: renderer.cl:275-290
   RM_DEV v3 atmosphere(const Sample& s, v3 ro, v3 rdir, float dist, v3 col) {
     const RmOpts& o = *sc.o;
-    const float fa = 1.0f - rmd::exp_det(dist * dist * -o.fogPow);
+    const float fa = 1.0f - M::exp(dist * dist * -o.fogPow);
     const v3 sk = sky(rdir);
-    col = V((sk.x - col.x) * fa + col.x, (sk.y - col.y) * fa + col.y, (sk.z - col.z) * fa + col.z);
+    col = mads(sk - col, fa, col);
     const int nl = o.numLights;
     for (int i = 0; i < nl; i++) {
       v3 lp = light_at(s, i);
-      const float d = rmd::clamp_cl(dot(lp - ro, rdir), 0.0f, dist);
+      const float d = M::clamp(dot(lp - ro, rdir), 0.0f, dist);
       lp = mads(rdir, d, ro - lp);
       const float k = o.flareAmp / dot(lp, lp);
       col = mads(ld3(o.lightColor[i]), k, col);
@@ -840,11 +828,11 @@ struct Tracer {
 #endif
     march(p, ldir, h, lmax, sc.o->shadowIter, false, true);
     RM_WS(ws_kind = ws_saved);
-    return rmd::step_cl(lmax, h.distance);
+    return M::step(lmax, h.distance);
   }
-  RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) { return schlick_of(r0, smooth, n, view); }
+  RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) { return schlick_of<M>(r0, smooth, n, view); }
   RM_DEV float blinn_phong(float smooth, v3 raydir, v3 ldir, v3 n) {
-    return blinn_phong_of(smooth, raydir, ldir, n);
+    return blinn_phong_of<M>(smooth, raydir, ldir, n);
   }
   // renderer.cl:327-346
   RM_DEV float occlusion(const Sample& s, v3 pos, v3 normal) {
@@ -870,7 +858,7 @@ struct Tracer {
       scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false,
                      ACCEL ? ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2) : 0x7fffffff);
       RM_WS(ws_kind = ws_saved);
-      ao *= 1.0f - rmd::fmax_cl((d - sd) * o.aoAmp / d, 0.0f);
+      ao *= 1.0f - M::fmax((d - sd) * o.aoAmp / d, 0.0f);
     }
     return ao;
   }
@@ -889,12 +877,12 @@ struct Tracer {
       const float att = 1.0f / d2;
       if (att > o.minLightAtt) {
         const v3 ldir = normalize(dl);
-        const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
-        const float sh = SDFM ? soft_shadow_sdf(mads(ldir, o.shadowBias, hitpos), ldir, lmax)
-                              : shadow_term(mads(ldir, o.shadowBias, hitpos), ldir, lmax);
+        const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
+        const float sh = SDFM ? soft_shadow_sdf(muladd(ldir, o.shadowBias, hitpos), ldir, lmax)
+                              : shadow_term(muladd(ldir, o.shadowBias, hitpos), ldir, lmax);
         if (sh > 0.0f) {
           const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-          diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+          diff = diff + inc * M::fmax(0.0f, dot(ldir, normal));
           spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
         }
       }
@@ -931,7 +919,7 @@ struct Tracer {
     } else {
       if (COUNT) cnt.primary_hits++;
       const Material m = material(h.objectID);
-      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      const float k = 1.0f / M::mad(m.smoothness, 200.0f, 5.0f);
       const v3 norm = mads(s.mcNormal, k, h.normal);
       v3 refl = V(0.f, 0.f, 0.f);
       if (m.r0 > 0.0f && o.reflectIter > 0) {
@@ -941,7 +929,7 @@ struct Tracer {
         v3 dir = rdir;
         for (int i = 0; i < o.reflectIter; i++) {
           dir = reflect(dir, rh.normal);
-          const v3 from = mads(dir, 0.0075f, rh.pos);
+          const v3 from = muladd(dir, 0.0075f, rh.pos);
           refl = refl + bounce_colour(s, from, dir, rh);
           if (rh.objectID < 0) break;
           if ((double)material(rh.objectID).r0 < 0.001) break;
@@ -1094,7 +1082,7 @@ struct Tracer {
       float d = 0.0f;
       for (int i = 0; i < np && (double)ao > 0.01; i++) {  // renderer.cl:338-344
         d += o.aoStepDist;
-        ao *= 1.0f - rmd::fmax_cl((d - lds_res(i, dl.lane)) * o.aoAmp / d, 0.0f);
+        ao *= 1.0f - M::fmax((d - lds_res(i, dl.lane)) * o.aoAmp / d, 0.0f);
       }
     }
     wave_sync();  // the posted values are dead: the next shared phase may overwrite them
@@ -1170,11 +1158,11 @@ struct Tracer {
         const float att = 1.0f / d2;
         if (att > o.minLightAtt) {
           const v3 ldir = normalize(dlv);
-          const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
+          const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
           Hit h{};
           RM_CLK_T(ck_s1);
           RM_CLK_ADD(11, ck_s0, ck_s1);
-          march(mads(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
+          march(muladd(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
           lds_res(light, owner) = h.distance;
         }
       }
@@ -1247,7 +1235,7 @@ struct Tracer {
           const v3 ldir = normalize(dl);
           const v3 inc = ld3(o.lightColor[i]) * att;
           clean &= finite_nonneg(inc);
-          const bool back = rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f;
+          const bool back = M::fmax(0.0f, dot(ldir, normal)) == 0.0f;
           if (back && !(dot(normalize(ldir - raydir), normal) > 0.0f)) dark |= 1u << i;
         }
       }
@@ -1277,18 +1265,18 @@ struct Tracer {
         const float att = 1.0f / d2;
         if (att > o.minLightAtt) {
           const v3 ldir = normalize(dl);
-          const float lmax = rmd::fmin_cl(rmd::sqrt_rn(d2) - o.shadowBias, o.maxDist);
-          const float sh = rmd::step_cl(lmax, lds_res(i, lane));
+          const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
+          const float sh = M::step(lmax, lds_res(i, lane));
 #ifdef RM_WORK_STATS
           ws_pairs++;
-          if (rmd::fmax_cl(0.0f, dot(ldir, normal)) == 0.0f) {
+          if (M::fmax(0.0f, dot(ldir, normal)) == 0.0f) {
             ws_pairs_back++;
             if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
           }
 #endif
           if (sh > 0.0f) {
             const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-            diff = diff + inc * rmd::fmax_cl(0.0f, dot(ldir, normal));
+            diff = diff + inc * M::fmax(0.0f, dot(ldir, normal));
             spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
           }
         }
@@ -1325,7 +1313,7 @@ struct Tracer {
     float r0 = 0.0f;
     if (hit) {
       const Material m = material(h.objectID);
-      const float k = 1.0f / (m.smoothness * 200.0f + 5.0f);
+      const float k = 1.0f / M::mad(m.smoothness, 200.0f, 5.0f);
       norm = mads(s.mcNormal, k, h.normal);
       r0 = m.r0;
     }
@@ -1345,7 +1333,7 @@ struct Tracer {
 #endif
         if (alive) {
           dir = reflect(dir, rh.normal);
-          from = mads(dir, 0.0075f, rh.pos);
+          from = muladd(dir, 0.0075f, rh.pos);
           RM_WS(ws_kind = 1);
           march(from, dir, rh, o.maxDist, o.maxIter, false);  // bounce_colour(), renderer.cl:383-405
           RM_WS(ws_kind = 0);

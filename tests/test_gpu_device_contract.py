@@ -1,0 +1,126 @@
+"""RM_CONTRACT_GFX950: the kernels reproduce, bit for bit, the pixels of the reference kernel
+itself as ROCm's OpenCL compiler builds it for this chip.
+
+The checker is oracle/_ref/renderer_gfx950_strict.hsaco -- the UNMODIFIED renderer.cl compiled
+where it lies (oracle/Makefile ref_gfx950: -ffp-contract=off, correctly rounded divide/sqrt) and
+linked by the clang driver against ROCm's own OpenCL built-in library; no stand-in for anything.
+It runs on the GPU through oracle/ref_gfx950_runner.cpp exactly as the reference host sequences
+its kernels (core.clj:76-97).  In this contract the product's built-ins ARE that library's
+functions (csrc/rm_math.hpp), so every float32 of the accumulator and every ARGB word must be
+equal -- whole frames, at every BASELINE configuration's full size."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def refs(oracle_mod):
+    if not oracle_mod.have_gfx950_ref("strict"):
+        pytest.skip("oracle/_ref/renderer_gfx950_strict.hsaco not built (needs /root/reference: build container)")
+    return oracle_mod
+
+
+def _differing(a, b):
+    return int((np.asarray(a).view(np.uint32) != np.asarray(b).view(np.uint32)).reshape(-1, 4).any(axis=1).sum())
+
+
+@pytest.mark.parametrize("name", list(scenes.SCENES))
+def test_fixture_scenes_every_kernel(native, refs, monkeypatch, name):
+    """Frame kernel (accelerated), single-pass kernels, the frame tiled over 3 ranks inside the
+    library, and the plain table-free kernels: all equal to the reference build."""
+    sc = scenes.build(name)
+    n = sc["n"]
+    want, want_argb, _ = refs.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], n, build="strict")
+    with native.Context(0) as ctx:
+        ctx.set_contract("gfx950")
+        ctx.set_volume(sc["vox"], sc["vres"])
+        px, argb = ctx.render_frame(sc["opts"], sc["mc"], n)
+        assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
+        acc = np.zeros(4 * n, np.float32)
+        for i in range(sc["iter"]):
+            ctx.render_image(np.ascontiguousarray(sc["mc"][i]), sc["opts"][i * 544:(i + 1) * 544], acc, n=n)
+        assert _differing(acc, want) == 0
+        assert np.array_equal(ctx.tonemap_image(acc, sc["opts"][:544], n=n), want_argb)
+    with native.Context([0, 0, 0]) as ctx:
+        ctx.set_contract("gfx950")
+        ctx.set_volume(sc["vox"], sc["vres"])
+        px, argb = ctx.render_frame(sc["opts"], sc["mc"], n)
+        assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
+    monkeypatch.setenv("RAYMARCH_NO_ACCEL", "1")
+    with native.Context(0) as ctx:
+        ctx.set_contract("gfx950")
+        ctx.set_volume(sc["vox"], sc["vres"])
+        px, argb = ctx.render_frame(sc["opts"], sc["mc"], n)
+        assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
+
+
+@pytest.mark.parametrize("passes,pack", [(8, "3"), (16, "4"), (12, "4"), (25, "4")])
+def test_pass_packed_wavefronts(native, refs, monkeypatch, passes, pack):
+    spec = dict(vol="gyroid", vres=64, w=56, h=40, iter=passes, mat="metal", theta=-30, dist=2.2, dof=0.02)
+    sc = scenes.build(spec, mc_seed=500)
+    monkeypatch.setenv("RAYMARCH_PASS_PACK", pack)
+    want, want_argb, _ = refs.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"], build="strict")
+    with native.Context(0) as ctx:
+        ctx.set_contract("gfx950")
+        ctx.set_volume(sc["vox"], sc["vres"])
+        px, argb = ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+    assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
+
+
+@pytest.mark.parametrize("config", ["c1", "c2", "c3", "c4", "c5"])
+def test_baseline_configurations_whole_frames(native, refs, config):
+    """Every BASELINE configuration at its full size, the WHOLE frame: the reference kernel renders
+    it on this GPU (C2: 16 launches, ~0.25 s; C4: 64 launches over 8.3 M pixels), the product renders
+    it in one launch; all floats and all ARGB words equal."""
+    import bench
+
+    wl = bench.WORKLOADS[config]
+    vox, vres, opts, mc = bench.build_inputs(wl)
+    n = wl["w"] * wl["h"]
+    want, want_argb, ref_ms = refs.gfx950_render_frame(vox, opts, mc, n, build="strict")
+    with native.Context(0) as ctx:
+        ctx.set_contract("gfx950")
+        ctx.set_volume(vox, vres)
+        px, argb = ctx.render_frame(opts, mc, n)
+        ms, launches = ctx.last_frame_timing()
+    bad = _differing(px, want)
+    print(f"{config}: {n} pixels x {wl['spp']} passes -- reference kernel {ref_ms:.1f} ms, this path {ms:.2f} ms "
+          f"({ref_ms / ms:.0f}x), {bad} differing pixels")
+    assert bad == 0
+    assert np.array_equal(argb, want_argb)
+    assert len(np.unique(px.reshape(-1, 4)[::97, :3])) > 1000  # a real image
+
+
+def test_contract_is_per_context_and_switchable(native, refs, oracle_mod):
+    """The same context renders both contracts; each equals its own checker."""
+    sc = scenes.build("orange_dof_2spp")
+    n = sc["n"]
+    want_dev, _, _ = refs.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], n, build="strict")
+    want_cpu, _ = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], n)
+    with native.Context(0) as ctx:
+        ctx.set_volume(sc["vox"], sc["vres"])
+        for _ in range(2):
+            ctx.set_contract("gfx950")
+            assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_dev) == 0
+            ctx.set_contract("cpu")
+            assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_cpu) == 0
+    assert _differing(want_dev, want_cpu) > 0
+
+
+def test_randomised_frames_against_the_reference_build(refs):
+    """tools/fuzz_parity.py in the device contract: random volumes, cameras (inside and around),
+    presets, record overrides, pass counts -- the reference kernel on the GPU is the checker."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--contract", "gfx950",
+                        "--cases", "60", "--seed", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

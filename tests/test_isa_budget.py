@@ -15,7 +15,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0ELb0"
+KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0ELi0E"
 
 
 @pytest.fixture(scope="module")

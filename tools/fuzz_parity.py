@@ -21,6 +21,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--contract", default="cpu", choices=["cpu", "gfx950"],
+                    help="cpu: kernels in the OpenCL-CPU-device contract against the CPU restatement; gfx950: kernels "
+                         "in the device contract against the reference kernel built for gfx950 (strict build), on the GPU")
     args = ap.parse_args()
 
     import oracle
@@ -33,8 +36,9 @@ def main():
             ("gyroid", 128), ("gyroid", 256), ("terrain", 128)]
     sparse = gen.make_blob_volume(64, radius=(0.01, 0.03))
     mats = sorted(materials.presets)
-    bad = 0
+    bad = skipped = 0
     ctx = _native.Context(0)
+    ctx.set_contract(args.contract)
     for case in range(args.cases):
         kind, vres = vols[int(rng.integers(len(vols)))]
         vox = sparse if (kind == "blobs" and rng.random() < 0.5) else scenes.volume(kind, vres)
@@ -103,6 +107,15 @@ def main():
         mask = np.zeros(n, np.uint8)
         for i in range(it):
             oracle.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], want, n=n, undefined_mask=mask)
+        if args.contract == "gfx950":
+            # The checker is the reference kernel itself.  A work-item whose material index leaves
+            # the record (undefined in the reference, renderer.cl:394,418) makes that kernel read its
+            # private copy of the record out of bounds -- on this chip a memory access fault that
+            # takes the process down -- so frames the restatement marks are not given to it.
+            if mask.any():
+                skipped += 1
+                continue
+            want, _, _ = oracle.gfx950_render_frame(vox, opts, mc, n, build="strict", tonemap=False)
         ctx.set_volume(vox, vres3)
         px, _ = ctx.render_frame(opts, mc, n)
         ok = np.repeat(mask == 0, 4)
@@ -114,7 +127,8 @@ def main():
             print(f"MISMATCH case {case}: {diff} floats; volume {kind} {vres}, base {base}, over {over}, mc seed {seed}, n {n}",
                   flush=True)
     ctx.close()
-    print(f"{args.cases} cases, {bad} mismatching")
+    print(f"{args.cases} cases ({args.contract} contract), {bad} mismatching" +
+          (f", {skipped} not run (a work-item with an undefined material index)" if skipped else ""))
     return 1 if bad else 0
 
 

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 src, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 jobs = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0"
+KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0ELi0E"
 
 
 def score(path):
