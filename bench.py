@@ -144,7 +144,7 @@ def main():
                          "build on the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -278,7 +278,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": "render_frame_kernel<accel, %s waves/SIMD>" % os.environ.get("RAYMARCH_WAVES_PER_SIMD", "7"), "kernel_ms": round(pass_ms, 4),
+                "kernel": "render_frame_kernel<accel, 7 waves/SIMD>", "kernel_ms": round(pass_ms, 4),
                 "launches_per_frame": launches,
                 "alg_bytes_per_launch": int(alg_bytes_launch),
                 "alg_bytes_per_sample": round(alg_bytes_frame / samples_per_frame, 1),

@@ -207,27 +207,6 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
   }
 }
 
-// A/B (-DRM_COARSE=1, not the default): per 4x4x4-cell block the SMALLEST value of each of the
-// nine tables -- a lower bound of every cell's value in the block, hence a valid (shorter) skip
-// distance.  (R/4)^3 bytes per table: 2.4 MB for nine tables at 256^3, resident in every XCD's L2.
-__global__ __launch_bounds__(256) void coarse_kernel(const uint8_t* __restrict__ tabs, Dim d, int ntab,
-                                                     uint8_t* __restrict__ coarse) {
-  const int bx = (d.rx + 3) >> 2, by = (d.ry + 3) >> 2, bz = (d.rz + 3) >> 2;
-  const long long blocks = (long long)bx * by * bz, total = (long long)d.rx * d.ry * d.rz;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < blocks * ntab;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int t = (int)(i / blocks);
-    const long long b = i % blocks;
-    const int x0 = (int)(b % bx) * 4, y0 = (int)((b / bx) % by) * 4, z0 = (int)(b / ((long long)bx * by)) * 4;
-    int m = 255;
-    for (int z = z0; z < min(z0 + 4, d.rz); z++)
-      for (int y = y0; y < min(y0 + 4, d.ry); y++)
-        for (int x = x0; x < min(x0 + 4, d.rx); x++)
-          m = min(m, (int)tabs[(long long)t * total + ((long long)z * d.ry + y) * d.rx + x]);
-    coarse[i] = (uint8_t)m;
-  }
-}
-
 // dist8 from the eight directional tables: the nearest obstacle lies in one of the closed
 // octants around the cell, so the Chebyshev distance is the smallest of the eight cube edges
 __global__ __launch_bounds__(256) void dist_from_oct_kernel(const uint8_t* __restrict__ oct8, long long total,
@@ -301,16 +280,6 @@ hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, i
   }
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
   dist_from_oct_kernel<<<blocks, 256, 0, st>>>(oct, total, d_dist9);
-  return hipGetLastError();
-}
-
-long long coarse_bytes(int rx, int ry, int rz, int ntab) {
-  return (long long)((rx + 3) >> 2) * ((ry + 3) >> 2) * ((rz + 3) >> 2) * ntab;
-}
-hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, int rz, int ntab, uint8_t* d_coarse) {
-  const long long n = coarse_bytes(rx, ry, rz, ntab);
-  const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
-  coarse_kernel<<<blocks, 256, 0, st>>>(d_tabs, Dim{rx, ry, rz}, ntab, d_coarse);
   return hipGetLastError();
 }
 

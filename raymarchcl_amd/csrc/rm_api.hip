@@ -69,7 +69,7 @@ struct Volume {
   std::mutex mu;
   int device = 0;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
-  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf, coarse_buf;
+  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf;
   int rx = 0, ry = 0, rz = 0;
   int accel_iso = -1;              // isoVal the tables were built for, -1 = stale
   unsigned long long oct_stride = 0;
@@ -78,7 +78,7 @@ struct Volume {
   double accel_build_ms = 0.0;     // wall time of the last table build (reported by bench.py)
   ~Volume() {
     (void)hipSetDevice(device);
-    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release(); coarse_buf.release();
+    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release();
   }
 };
 
@@ -97,9 +97,9 @@ struct rm_ctx {
   int pack_waste = 60;       // RAYMARCH_PACK_WASTE: % of lane turns a partial last group may leave without a
                              // pass (their lanes still trace other lanes' secondary rays: 25 passes as
                              // 16 + 9 measured 12 % faster than as 6 x 4 + 1)
-  int waves_per_simd = 7;    // RAYMARCH_WAVES_PER_SIMD (4..8): register budget of the frame kernel
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
+  bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
   int contract = 0;          // rm_set_contract: RM_CONTRACT_CPU_DEVICE (default) / RM_CONTRACT_GFX950
   // records validated by rm_check_device_opts
@@ -177,7 +177,7 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     // Row-major tables have the cheapest index arithmetic and win while the Infinity Cache
     // catches most misses (bricks: +3 % at 256^3, equal at 512^3); far beyond it every miss
     // goes to HBM and locality wins (1024^3: -6.6 %)
-    const bool bricked = oct && RM_COARSE == 0 &&
+    const bool bricked = oct &&
                          (c->bricks >= 0 ? c->bricks == 1 : vox * 13 > ((size_t)4 << 30));
     const size_t tbytes = bricked ? (size_t)rmk::bricked_bytes(v.rx, v.ry, v.rz) : vox;
     hipEvent_t t0 = c->ev_b0, t1 = c->ev_b1;
@@ -198,10 +198,6 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
       HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
                                static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
     }
-#if RM_COARSE
-    HIP_TRY(v.coarse_buf.reserve((size_t)rmk::coarse_bytes(v.rx, v.ry, v.rz, tables)));
-    HIP_TRY(rmk::build_coarse(c->stream, lin, v.rx, v.ry, v.rz, tables, static_cast<uint8_t*>(v.coarse_buf.p)));
-#endif
     HIP_TRY(hipEventRecord(t1, c->stream));
     // contexts that share the volume run on other streams: the tables are complete before
     // anybody else can see accel_iso
@@ -213,11 +209,15 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   }
   out->oct_stride = v.oct_stride;
   out->bricked = v.bricked;
+  // cubic power-of-two grid whose tables stay below 4 GiB: shift-or cell index, 32-bit buffer offsets
+  if (!v.bricked && v.rx == v.ry && v.ry == v.rz && (v.rx & (v.rx - 1)) == 0 && v.rx >= 2 &&
+      vox * (v.oct_stride ? 9 : 1) < ((size_t)1 << 32) && c->pow2_tables) {
+    unsigned k = 0;
+    while ((1 << k) < v.rx) k++;
+    out->log2res = k;
+  }
   out->dist = static_cast<const uint8_t*>(v.dist_buf.p);
   out->surf = static_cast<const uint32_t*>(v.surf_buf.p);
-#if RM_COARSE
-  out->coarse = static_cast<const uint8_t*>(v.coarse_buf.p);
-#endif
   return RM_OK;
 }
 
@@ -314,7 +314,6 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.argb = i1 == iter ? out.argb : nullptr;
     f.resx = resx; f.n = n; f.passes = i1 - i0;
     f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
-    f.min_waves = c->waves_per_simd;
     f.pp_log2 = rmk::choose_pass_pack(i1 - i0, c->pass_pack, c->pack_waste);
     f.xcd_rows = c->xcd_rows;
     f.accumulate = i0 > 0;
@@ -411,8 +410,8 @@ static int create_one(int device_id, rm_ctx** out) {
   if (bk && (bk[0] == '0' || bk[0] == '1')) c->bricks = bk[0] - '0';
   const char* pw = getenv("RAYMARCH_PACK_WASTE");
   if (pw && atoi(pw) >= 0 && atoi(pw) <= 100) c->pack_waste = atoi(pw);
-  const char* sw = getenv("RAYMARCH_WAVES_PER_SIMD");
-  if (sw && atoi(sw) >= 4 && atoi(sw) <= 8) c->waves_per_simd = atoi(sw);
+  const char* p2 = getenv("RAYMARCH_POW2");
+  if (p2) c->pow2_tables = p2[0] != '0';
   *out = c;
   return RM_OK;
 }
@@ -467,7 +466,6 @@ void rm_destroy(rm_ctx* c) {
   }
   c->peers.clear();
   (void)hipSetDevice(c->device);
-  rmk::dump_work_stats();
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
                     &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf};

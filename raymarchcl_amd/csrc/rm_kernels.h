@@ -11,25 +11,19 @@ struct Counters;
 inline int tiles_per_part(int tiles, int parts) { return (tiles + parts - 1) / parts; }
 // number of 8x8 tiles covering work-items 0..n-1 of an image `resx` wide
 int tiles_total(int resx, int n);
-void dump_work_stats();  // no-op unless built with -DRM_WORK_STATS
 
-#ifndef RM_COARSE
-#define RM_COARSE 0  // A/B: consult a 4^3-block minimum of the tables before the fine fetch (host and device agree)
-#endif
 struct Accel {  // nullptrs = not available: the kernels then run the plain fixed-step march
   const uint8_t* dist = nullptr;
   const uint32_t* surf = nullptr;
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
   unsigned long long oct_stride = 0;
-  const uint8_t* coarse = nullptr;  // RM_COARSE: block minima of the 1 or 9 tables, table-major
   bool bricked = false;             // dist / oct tables in 8x4x4-cell bricks of 128 B (oct_stride = bricked table bytes)
+  unsigned log2res = 0;             // > 0: cubic grid of edge 1 << log2res, row-major tables below 4 GiB (walk_step LAYOUT 2)
 };
 // bytes of one byte table in the bricked layout
 long long bricked_bytes(int rx, int ry, int rz);
 // bricked table -> row-major (test hooks)
 hipError_t launch_unbrick(hipStream_t st, const uint8_t* d_bricked, int rx, int ry, int rz, uint8_t* d_linear);
-long long coarse_bytes(int rx, int ry, int rz, int ntab);
-hipError_t build_coarse(hipStream_t st, const uint8_t* d_tabs, int rx, int ry, int rz, int ntab, uint8_t* d_coarse);
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
@@ -48,7 +42,7 @@ struct FrameLaunch {
   float* acc = nullptr;            // float4 accumulators: tile-major [tiles_per_part][64], or the row-major image
   uint32_t* argb = nullptr;        // row_major only, nullable: TonemapImage output, written with the last pass
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
-  int min_waves = 7, pp_log2 = 0;
+  int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
   // arithmetic contract (rm_math.hpp): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
   // the seed casts (rm_set_seed_cast), 2 = ROCm's OpenCL library on this GPU (rm_set_contract)

@@ -7,9 +7,9 @@
 //   prims_kernel         -- device side of rm_selftest_prims.
 //
 // Work decomposition: the image is cut into 8x8-pixel tiles (row-major tile
-// order); one 64-lane wavefront owns one tile so that the rays of a wave are
-// spatially coherent (their voxel fetches share cache lines), four tiles per
-// 256-thread workgroup.  Everything that is uniform across the launch (the
+// order); a workgroup is ONE 64-lane wavefront (finest dispatch granularity) that owns a tile
+// (single-pass kernels) or a 2x2-pixel block of a tile x 16 passes (frame kernel), so that the
+// rays of a wave are coherent (their table fetches share cache lines).  Everything that is uniform across the launch (the
 // 544-byte option record) is read through a uniform pointer, i.e. by scalar
 // loads into SGPRs -- the reference's per-work-item private copy of the record
 // is what costs it 560 B of scratch per lane on this chip.
@@ -21,16 +21,7 @@
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
 
-#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
-// debug build only (hipcc -DRM_WORK_STATS): what render_samples_kernel executes, summed
-// over all lanes: samples, outer marches, their turns, filtered turns, voxel walks,
-// dist8 fetches, samples advanced, AO loops.  rmk::dump_work_stats() prints and resets.
-__device__ unsigned long long g_work_stats[64];
-#endif
 
-#ifndef RM_WAVE_SHARE
-#define RM_WAVE_SHARE 1  // AO probes and shadow rays of a wavefront's hits dealt to all its lanes
-#endif
 
 namespace {
 
@@ -66,13 +57,14 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
 // resolve_kernel.
 // DEVICE: the arithmetic contract -- false: OpenCL CPU device (seed-cast lowering chosen at run
 // time), true: ROCm's OpenCL library on this GPU (rm_math.hpp)
-template <bool COUNT, bool TILE_MAJOR, bool ACCEL, bool BRICK = false, bool DEVICE = false>
+template <bool COUNT, bool TILE_MAJOR, bool ACCEL, int LAYOUT = 0, bool DEVICE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
     const RmOpts* __restrict__ opts,
     float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
-    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0, int seed_cast_gpu = 0) {
+    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0, int seed_cast_gpu = 0,
+    unsigned log2res = 0) {
   const int resx = opts->resolution[0];
   const TileGeom g = tile_geom(resx, n);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -82,8 +74,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
   rmk::Scene sc{vox, mc, opts, dist8, surf32, oct_stride};
   sc.seed_cast_gpu = seed_cast_gpu;
+  sc.log2res = log2res;
   using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<2>>::type;
-  rmk::Tracer<COUNT, ACCEL, false, BRICK, M> tr(sc);
+  rmk::Tracer<COUNT, ACCEL, false, LAYOUT, M> tr(sc);
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
     const float fb = opts->frameBlend;
@@ -125,14 +118,13 @@ struct FrameArgs {
   const uint32_t* __restrict__ surf32;
   unsigned long long oct_stride;
   const float* __restrict__ sdf;
-  const uint8_t* __restrict__ coarse;  // RM_COARSE A/B
   const float4* __restrict__ mc_all;   // scatter table of the launch's first pass
   const RmOpts* __restrict__ opts_all; // record of the launch's first pass
   const RmOpts* __restrict__ opts0;    // record 0 of the frame (TonemapImage reads its gamma)
   float4* __restrict__ acc;            // tile-major partition accumulators, or the row-major image
   uint32_t* __restrict__ argb;         // row-major ARGB, or nullptr
   int n, resx, tile_first, tile_stride, tiles_per_part, pp_log2, passes, bpr;
-  long long total_blocks;              // RM_PERSISTENT: blocks of the frame (the grid is smaller)
+  unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int row_major;                       // acc is indexed by work-item id instead of slot*64 + pixel
 };
@@ -151,15 +143,12 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 
 // MULTI = the launch holds more passes than a wavefront does (the loop over groups of passes
 // exists only then: a single group keeps nothing alive across the body of a sample)
-#ifndef RM_PERSISTENT
-#define RM_PERSISTENT 0  // A/B: a resident grid whose wavefronts stride over the frame's blocks
-#endif
 // ARITH: 0 = OpenCL CPU device arithmetic and casts, 1 = the same with the GPU lowering of the seed
 // casts, 2 = ROCm's OpenCL library on this GPU (rm_math.hpp)
-template <bool ACCEL, bool SDFM, bool MULTI, bool BRICK, int ARITH>
+template <bool ACCEL, bool SDFM, bool MULTI, int LAYOUT, int ARITH>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
   using M = typename std::conditional<ARITH == 2, rmk::MathOcl, rmk::MathX86<(ARITH == 1 ? 1 : 0)>>::type;
-  using Tr = rmk::Tracer<false, ACCEL, SDFM, BRICK, M>;
+  using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
   const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
   const int ppw = 64 >> pp_log2;            // pixels per wavefront
@@ -199,19 +188,12 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     const float4 p = a.acc[at];
     px = p.x; py = p.y; pz = p.z;
   }
-#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
-  unsigned long long ws_acc[64];
-  for (int k = 0; k < 64; k++) ws_acc[k] = 0ull;
-#endif
   for (int c0 = 0; MULTI ? c0 < a.passes : c0 == 0; c0 += MULTI ? pp : 1) {
     const int pass = c0 + pl;
-#ifdef RM_AB_NOLIVE
-    const bool live = true;  // (A/B only: valid when passes is a multiple of pp)
-#else
     const bool live = pass < a.passes;
-#endif
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
-    rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf, a.coarse};
+    rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
+    sc.log2res = a.log2res;
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
@@ -237,59 +219,18 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
       py = M::mix(py, col.y, fb);
       pz = M::mix(pz, col.z, fb);
     }
-#ifdef RM_PHASE_CLOCK
-    for (int k = 0; k < 5; k++) ws_acc[32 + k] += tr.ws_clk[k];
-    for (int k = 5; k < 13; k++) ws_acc[56 + k - 5] += tr.ws_clk[k];
-    if (tr.ws_now()) ws_acc[37] += 1ull;
-#endif
-#ifdef RM_WORK_STATS
-    if (live) {
-      ws_acc[43] += tr.ws_redo;
-      for (int k = 0; k < 3; k++) { ws_acc[48 + k] += tr.ws_k_est[k]; ws_acc[52 + k] += tr.ws_k_filt[k]; }
-      for (int k = 0; k < 4; k++) ws_acc[44 + k] += tr.ws_k_nohit[k];
-      ws_acc[38] += tr.ws_k_one[0] + tr.ws_k_one[1];
-      ws_acc[39] += tr.ws_k_one[2];
-      ws_acc[40] += tr.ws_pairs; ws_acc[41] += tr.ws_pairs_back; ws_acc[42] += tr.ws_pairs_dark; ws_acc[51] += tr.ws_pairs_skipped;
-      ws_acc[0] += 1;
-    }
-    for (int k = 0; k < 3; k++) { ws_acc[32 + k] += tr.ws_k_follow[k]; ws_acc[35 + k] += tr.ws_k_follow_ground[k]; }
-    ws_acc[55] += tr.ws_sh[0];
-    for (int k = 1; k < 6; k++) ws_acc[58 + k] += tr.ws_sh[k];  // (56..63 hold phase clocks in the other debug build)
-    {
-      const unsigned int v[32] = {0u, tr.ws_rays, tr.ws_iters, tr.ws_filtered, tr.ws_walks, tr.ws_lookups,
-                                  tr.ws_steps, tr.ws_probes, tr.wv_walk, tr.wv_filt, tr.wv_est};
-      for (int k = 1; k < 11; k++) ws_acc[k] += v[k];
-      for (int k = 0; k < 4; k++) {
-        ws_acc[11 + k] += tr.ws_k_walks[k]; ws_acc[15 + k] += tr.ws_k_fetch[k]; ws_acc[19 + k] += tr.ws_k_slots[k];
-      }
-      for (int k = 0; k < 6; k++) ws_acc[23 + k] += tr.ws_dhist[k];
-      ws_acc[29] += tr.ws_adds_hit; ws_acc[30] += tr.ws_adds_nohit; ws_acc[31] += tr.ws_adds_lazy;
-    }
-#endif
   }
   if (first) {
     a.acc[at] = make_float4(px, py, pz, 1.0f);
     if (a.argb) a.argb[id] = tonemap_argb<M>(px, py, pz, a.opts0->gamma);
   }
-#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
-  for (int k = 0; k < 64; k++)
-    if (ws_acc[k]) atomicAdd(&g_work_stats[k], ws_acc[k]);
-#endif
 }
 
-template <bool ACCEL, int MINW, bool SDFM, bool MULTI, bool BRICK = false, int ARITH = 0>
+template <bool ACCEL, int MINW, bool SDFM, bool MULTI, int LAYOUT = 0, int ARITH = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
   __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
-#if RM_PERSISTENT
-  // (stride = grid size, a multiple of 8: a wavefront stays on the tile rows of its XCD)
-  for (long long b = blockIdx.x; b < a.total_blocks; b += gridDim.x) {
-    frame_block<ACCEL, SDFM, MULTI, BRICK, ARITH>(a, b, wave_lds);
-    __syncthreads();
-  }
-#else
-  frame_block<ACCEL, SDFM, MULTI, BRICK, ARITH>(a, blockIdx.x, wave_lds);
-#endif
+  frame_block<ACCEL, SDFM, MULTI, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
 }
 
 template <bool DEVICE>
@@ -368,7 +309,7 @@ __global__ void filter_check_kernel(const float* __restrict__ rays, const RmOpts
   const rmk::v3 rpos = rmk::muladd(rd, t, ro);  // the position march() hands to the estimate
   const float t_in = rmk::box_entry_of<rmk::MathX86<0>>(*opts, rpos, rd);
   const RmOpts& o = *opts;
-  const float m = 1e-4f;  // scene_distance's RM_INSIDE_TEST margin
+  const float m = 1e-4f;  // the margin of scene_distance's inside-the-box shortcut
   const bool inside = (rpos.x - o.voxelBoundsMin[0] > m) & (o.voxelBoundsMax[0] - rpos.x > m) &
                       (rpos.y - o.voxelBoundsMin[1] > m) & (o.voxelBoundsMax[1] - rpos.y > m) &
                       (rpos.z - o.voxelBoundsMin[2] > m) & (o.voxelBoundsMax[2] - rpos.z > m);
@@ -393,73 +334,6 @@ hipError_t launch_filter_check(hipStream_t st, const float* rays, const RmOpts* 
 
 int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
-void dump_work_stats() {
-#ifdef RM_WORK_STATS
-  unsigned long long h[64] = {0};
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
-  const double n = h[0] ? (double)h[0] : 1.0;
-  fprintf(stderr, "[work stats] samples=%llu per sample: marches=%.2f turns=%.2f filtered=%.2f walks=%.2f "
-                  "fetches=%.2f steps_advanced=%.2f ao_loops=%.2f\n",
-          h[0], h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n, h[7] / n);
-  fprintf(stderr, "[work stats] lane utilisation of the loops: walk %.1f%% (fetches / lane-slots), "
-                  "filtered turns %.1f%%, estimate turns %.1f%%\n",
-          100.0 * h[5] / (h[8] ? h[8] : 1), 100.0 * h[2] / (h[9] ? h[9] : 1),
-          100.0 * (h[2] - h[3]) / (h[10] ? h[10] : 1));
-  static const char* kind[4] = {"primary march", "reflection march", "shadow march", "AO probe"};
-  for (int k = 0; k < 4; k++)
-    fprintf(stderr, "[work stats]   %-16s %.2f walks/sample, %.1f fetches/walk, %.1f%% of the walk lane-slots at "
-                    "%.1f%% utilisation\n",
-            kind[k], h[11 + k] / n, (double)h[15 + k] / (h[11 + k] ? h[11 + k] : 1),
-            100.0 * h[19 + k] / (h[8] ? h[8] : 1), 100.0 * h[15 + k] / (h[19 + k] ? h[19 + k] : 1));
-  fprintf(stderr, "[work stats] fetched dist8 values: hit %.1f%%, 1: %.1f%%, 2: %.1f%%, 3: %.1f%%, 4-7: %.1f%%, "
-                  "8+: %.1f%%\n",
-          100.0 * h[23] / h[5], 100.0 * h[24] / h[5], 100.0 * h[25] / h[5], 100.0 * h[26] / h[5],
-          100.0 * h[27] / h[5], 100.0 * h[28] / h[5]);
-  fprintf(stderr, "[work stats] samples advanced per sample: %.1f in walks that hit, %.1f in walks that do not "
-                  "(%.1f of them after the walk's last fetch with value <= 1)\n",
-          h[29] / n, h[30] / n, h[31] / n);
-  fprintf(stderr, "[work stats] (hit, light) pairs per sample %.2f: %.1f%% face away from the light, %.1f%% of all have "
-                  "no specular term either (%.1f%% of all: shadow march not traced); last turn repeated for its normal in %.3f "
-                  "marches per sample\n",
-          h[40] / n, 100.0 * h[41] / (h[40] ? h[40] : 1), 100.0 * h[42] / (h[40] ? h[40] : 1),
-          100.0 * h[51] / (h[40] ? h[40] : 1), h[43] / n);
-  fprintf(stderr, "[work stats] estimate turns per sample that are not the first of their march (of which: found nothing closer "
-                  "than the ground term): primary %.2f (%.2f), reflection %.2f (%.2f), shadow %.2f (%.2f)\n",
-          h[32] / n, h[35] / n, h[33] / n, h[36] / n, h[34] / n, h[37] / n);
-  fprintf(stderr, "[work stats] shadow phases with tasks: %.0f, tasks per phase %.1f (%.1f%% without any estimate turn), "
-                  "rounds per phase %.2f (%.1f%% of the phases need more than one), rounds of marches WITH estimate turns if the "
-                  "others ran apart: %.2f\n",
-          (double)h[55], (double)h[61] / (h[55] ? h[55] : 1), 100.0 * h[62] / (h[61] ? h[61] : 1),
-          (double)h[59] / (h[55] ? h[55] : 1), 100.0 * h[63] / (h[55] ? h[55] : 1), (double)h[60] / (h[55] ? h[55] : 1));
-  fprintf(stderr, "[work stats] walks without a hit per sample: primary %.2f, reflection %.2f, shadow %.2f, AO %.2f; "
-                  "ended by their first fetch: primary+reflection %.2f, shadow %.2f\n",
-          h[44] / n, h[45] / n, h[46] / n, h[47] / n, h[38] / n, h[39] / n);
-  fprintf(stderr, "[work stats] turns per sample (estimate + filtered): primary %.2f + %.2f, reflection %.2f + %.2f, "
-                  "shadow %.2f + %.2f\n",
-          h[48] / n, h[52] / n, h[49] / n, h[53] / n, h[50] / n, h[54] / n);
-#endif
-#ifdef RM_PHASE_CLOCK
-  {
-    unsigned long long h[64] = {0};
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_work_stats), sizeof h);
-    const double waves = h[37] ? (double)h[37] : 1.0;
-    fprintf(stderr, "[phase clock] wave time by phase (shader clock ticks per wave): primary march %.0f, reflection "
-                    "marches %.0f, AO phases %.0f, shadow phases %.0f, shading arithmetic %.0f\n",
-            h[32] / waves, h[33] / waves, h[34] / waves, h[35] / waves, h[36] / waves);
-    fprintf(stderr, "[phase clock]   inside those: walk loops %.0f, estimate set-up %.0f, hit evaluation %.0f, filtered-turn "
-                    "loops %.0f, march set-up %.0f, AO task set-up %.0f, shadow task set-up %.0f; sample + camera %.0f\n",
-            h[56] / waves, (h[57] - h[56] - h[58]) / waves, h[58] / waves, h[59] / waves, h[60] / waves, h[61] / waves,
-            h[62] / waves, h[63] / waves);
-  }
-#endif
-#if defined(RM_WORK_STATS) || defined(RM_PHASE_CLOCK)
-  unsigned long long z[64] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_work_stats), z, sizeof z);
-#endif
-}
-
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
@@ -479,18 +353,22 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
     if (device_arith)                                                                                             \
       render_pass_kernel<C, T, A, B, true><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, px4, \
                                                                    n, id0, id1, tile_first, tile_stride,          \
-                                                                   d_counters, accel.oct_stride, seed_cast_gpu);  \
+                                                                   d_counters, accel.oct_stride, seed_cast_gpu,   \
+                                                                   accel.log2res);                                \
     else                                                                                                          \
       render_pass_kernel<C, T, A, B, false><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts,     \
                                                                     px4, n, id0, id1, tile_first, tile_stride,    \
-                                                                    d_counters, accel.oct_stride, seed_cast_gpu); \
+                                                                    d_counters, accel.oct_stride, seed_cast_gpu,  \
+                                                                    accel.log2res);                               \
   } while (0)
-  if (d_counters) { RM_LAUNCH(true, false, false, false); }
-  else if (acc && accel.bricked) { if (tile_major) RM_LAUNCH(false, true, true, true); else RM_LAUNCH(false, false, true, true); }
-  else if (tile_major && acc) { RM_LAUNCH(false, true, true, false); }
-  else if (tile_major) { RM_LAUNCH(false, true, false, false); }
-  else if (acc) { RM_LAUNCH(false, false, true, false); }
-  else { RM_LAUNCH(false, false, false, false); }
+  const int layout = accel.bricked ? 1 : (accel.log2res ? 2 : 0);
+  if (d_counters) { RM_LAUNCH(true, false, false, 0); }
+  else if (acc && layout == 1) { if (tile_major) RM_LAUNCH(false, true, true, 1); else RM_LAUNCH(false, false, true, 1); }
+  else if (acc && layout == 2) { if (tile_major) RM_LAUNCH(false, true, true, 2); else RM_LAUNCH(false, false, true, 2); }
+  else if (tile_major && acc) { RM_LAUNCH(false, true, true, 0); }
+  else if (tile_major) { RM_LAUNCH(false, true, false, 0); }
+  else if (acc) { RM_LAUNCH(false, false, true, 0); }
+  else { RM_LAUNCH(false, false, false, 0); }
 #undef RM_LAUNCH
   return hipGetLastError();
 }
@@ -530,7 +408,6 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.surf32 = f.accel.surf;
   a.oct_stride = f.accel.oct_stride;
   a.sdf = f.sdf;
-  a.coarse = f.accel.coarse;
   a.mc_all = reinterpret_cast<const float4*>(f.mc_all);
   a.opts_all = f.opts_all;
   a.opts0 = f.opts0;
@@ -540,20 +417,11 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.tiles_per_part = tpp; a.pp_log2 = pp_log2; a.passes = f.passes; a.bpr = bpr;
   a.accumulate = f.accumulate ? 1 : 0;
   a.row_major = f.row_major ? 1 : 0;
-  a.total_blocks = blocks;
-#if RM_PERSISTENT
-  {  // as many one-wavefront workgroups as the chip holds at the kernel's occupancy
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const long long resident = (long long)cus * 4 * f.min_waves * RM_PERSISTENT;
-    if (blocks > resident) blocks = resident;
-  }
-#endif
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   const bool multi = f.passes > (1 << pp_log2);
-#ifndef RM_GPUCAST_MINW
-#define RM_GPUCAST_MINW 7
+// (7 wavefronts per SIMD = 72 VGPRs measured best: 6 +3.5 %, 8 +2.5 %, 5 +14 %; -DRM_FRAME_MINW=n re-measures)
+#ifndef RM_FRAME_MINW
+#define RM_FRAME_MINW 7
 #endif
 #define RM_FRAME(A, W, S, B, G)                                                     \
   do {                                                                              \
@@ -566,23 +434,17 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
     else if (f.arith == 1) RM_FRAME(A, W, S, B, 1); \
     else RM_FRAME(A, W, S, B, 0);                   \
   } while (0)
+  a.log2res = f.accel.log2res;
   if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
-    if (f.arith == 1) RM_FRAME(false, 4, true, false, 1); else RM_FRAME(false, 4, true, false, 0);
+    if (f.arith == 1) RM_FRAME(false, 4, true, 0, 1); else RM_FRAME(false, 4, true, 0, 0);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
-    // (volumes whose tables exceed the caches: one register budget, the default)
-    RM_FRAME_ARITH(true, 7, false, true);
+    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 1);
+  } else if (f.accel.dist && f.accel.surf && f.accel.log2res) {
+    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 2);
   } else if (f.accel.dist && f.accel.surf) {
-    if (f.arith != 0) {  // (one register budget for the other contracts)
-      RM_FRAME_ARITH(true, RM_GPUCAST_MINW, false, false);
-    } else switch (f.min_waves) {
-      case 4: RM_FRAME(true, 4, false, false, 0); break;
-      case 5: RM_FRAME(true, 5, false, false, 0); break;
-      case 6: RM_FRAME(true, 6, false, false, 0); break;
-      case 8: RM_FRAME(true, 8, false, false, 0); break;
-      default: RM_FRAME(true, 7, false, false, 0); break;
-    }
+    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 0);
   } else {
-    RM_FRAME_ARITH(false, 3, false, false);
+    RM_FRAME_ARITH(false, 3, false, 0);
   }
 #undef RM_FRAME_ARITH
 #undef RM_FRAME

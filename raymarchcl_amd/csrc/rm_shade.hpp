@@ -31,15 +31,9 @@ struct Scene {
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
   unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
   const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
-  const uint8_t* __restrict__ coarse = nullptr;  // RM_COARSE A/B: 4^3-block minima of the tables
   int seed_cast_gpu = 0;  // (uint) casts of the seed expressions as a GPU device lowers them (rm_set_seed_cast)
+  unsigned log2res = 0;   // LAYOUT 2 (walk_step): edge of the cubic grid = 1 << log2res
 };
-#ifndef RM_COARSE
-#define RM_COARSE 0
-#endif
-#ifndef RM_COARSE_MIN
-#define RM_COARSE_MIN 6  // a block minimum of at least this many cells is used without the fine fetch
-#endif
 
 // ---- leaf routines; `o` points at the option record in device memory ----
 
@@ -118,72 +112,85 @@ RM_DEV v3 surf_normal(uint32_t w, bool smooth) {
 RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; }  // renderer.cl:205-207
 
 // One sample of the accelerated fixed-step walk (renderer.cl:219-234): look the
-// sample at p up in dist8 and move on.  `steps` = samples left including this one.
+// sample at p up in the skip table and move on.  `steps` = samples left including this one.
 // Returns 0: keep walking, 1: this sample is a hit (*cell_out = its cell, p kept),
 // 2: the walk ends without a hit (out of samples / left the grid / cannot reach
 // anything in the samples left).
 //
 // The samples that are skipped still advance p by the reference's sequential adds,
 // so the positions of all later samples -- and the hit position -- are bit-identical.
-// Skip length: dist8 = d at cell q means every cell within Chebyshev distance d-1
-// of q is empty and inside the grid.  Sample k lies <= k*s cells from sample 0
-// along the fastest axis (s = cells per sample), so its cell differs from q by at
-// most floor(k*s + eps) + 1; samples 1 .. j-1 are therefore certainly empty for
-// j = 1 + floor(0.98 * (d-1) / s)   (inv_s = 0.98 / s; the 2 % absorb the <= 0.01
-// cell of accumulated rounding drift and the rounding of p*res).
-// BRICK: the tables are stored in 8x4x4-cell bricks of 128 bytes = one cache line each
-// (rm_accel.hip), chosen by the host for volumes whose tables exceed the Infinity Cache: a ray's
-// consecutive fetches and the lanes of a wavefront then share lines instead of touching a new
-// 128-byte row segment per fetch.
-template <class M, bool BRICK = false>
-RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, int& steps, v3 delta,
-                     float inv_s, int* cell_out, unsigned long long table_off = 0, unsigned int* dhist = nullptr,
-                     const uint8_t* __restrict__ coarse = nullptr, unsigned int coarse_off = 0) {
-  // (M::cell: the bare conversion instruction; scene_distance has applied M::walk_guard)
-  const int qx = M::cell(p.x * (float)o.voxelRes[0]);
-  const int qy = M::cell(p.y * (float)o.voxelRes[1]);
-  const int qz = M::cell(p.z * (float)o.voxelRes[2]);
-  if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
-  // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
-  // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
+// Skip length: a table value d at cell q means every cell within Chebyshev distance d-1
+// of q (dist8) / of the cube of edge d ahead of the walk (oct8) is empty and inside the grid.
+// Sample k lies <= k*s cells from sample 0 along the fastest axis (s = cells per sample), so
+// its cell differs from q by at most floor(k*s + eps) + 1; samples 1 .. j-1 are therefore
+// certainly empty for
+//     j = 1 + floor(0.98 * (d-1) / s) = floor(d * inv_s + (1 - inv_s)),  inv_s = 0.98 / s
+// (the 2 % absorb the <= 0.01 cell of accumulated rounding drift, the rounding of p*res and of
+// the one fma that evaluates it; max(., 1) catches the rounding at d = 1).  Cells on a face of
+// the grid hold d = 1 -- also the cell a slightly negative coordinate truncates to
+// (renderer.cl:165) when the walk heads outward -- so no sample outside the grid is skipped.
+//
+// LAYOUT of the nine tables (chosen by the host per volume):
+//   0  row-major, 64-bit table offsets                                   (any grid)
+//   1  8x4x4-cell bricks of 128 bytes = one cache line each, 64-bit offsets: volumes whose
+//      tables exceed the Infinity Cache (a ray's consecutive fetches and the lanes of a
+//      wavefront share lines instead of touching a new row segment per fetch)
+//   2  row-major, cubic power-of-two grid, all tables below 4 GiB: the cell index is two
+//      shift-ors, the bounds test one compare of the or-ed coordinates, and the table is read
+//      through a buffer descriptor with a 32-bit offset (no 64-bit address arithmetic per
+//      fetch; out-of-range offsets read 0, so the fetch needs no guard)
+struct WalkTab {
+  const uint8_t* __restrict__ dist8;   // table 0; tables 1..8 follow at oct_stride
+  __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2: all nine tables as one buffer
+  unsigned res, sh;                    // LAYOUT 2: edge of the grid = 1 << sh
+  float fres;
+};
+template <class M, int LAYOUT>
+RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 delta, float inv_s, float c0,
+                     int* cell_out, unsigned long long table_off) {
+  int d, j;
   unsigned cell;
-  int d;
-  if (BRICK) {
-    const unsigned nbx = ((unsigned)o.voxelRes[0] + 7u) >> 3, nby = ((unsigned)o.voxelRes[1] + 3u) >> 2;
-    const unsigned brick = __umul24(__umul24((unsigned)qz >> 2, nby) + ((unsigned)qy >> 2), nbx) + ((unsigned)qx >> 3);
-    const unsigned within = ((((unsigned)qz & 3u) << 2 | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
-    cell = 0;
-    // (64-bit: the bricks of a 1024^3 table alone are 1 GiB; 9 tables follow each other)
-    d = dist8[(((unsigned long long)brick << 7) | within) + table_off];
-  } else {
-    cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
-                    (unsigned)o.voxelRes[0]) + (unsigned)qx;
-#if RM_COARSE
-    // block minimum first (a lower bound of the cell's value: a shorter but valid skip); the
-    // fine table only where the bound is too small to be useful
-    const unsigned bx = ((unsigned)o.voxelRes[0] + 3u) >> 2, by = ((unsigned)o.voxelRes[1] + 3u) >> 2;
-    const unsigned blk = __umul24(__umul24((unsigned)qz >> 2, by) + ((unsigned)qy >> 2), bx) + ((unsigned)qx >> 2);
-    d = coarse[coarse_off + blk];
-    if (d < RM_COARSE_MIN) d = dist8[cell + table_off];
-#else
-    d = dist8[cell + table_off];
-#endif
-  }
-  if (dhist) {  // stats build only
-    dhist[d < 4 ? d : (d < 8 ? 4 : 5)]++;
-    dhist[6] = (unsigned)d;
-  }
-  if (d == 0) {
-    if (BRICK)  // surf32 stays row-major
-      cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy, (unsigned)o.voxelRes[0]) +
-             (unsigned)qx;
+  if (LAYOUT == 2) {
+    // (M::cell: the bare conversion instruction; scene_distance has applied M::walk_guard)
+    const int qx = M::cell(p.x * tab.fres), qy = M::cell(p.y * tab.fres), qz = M::cell(p.z * tab.fres);
+    const bool ok = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < tab.res) & (steps > 0);  // renderer.cl:219, :221
+    cell = ((((unsigned)qz << tab.sh) | (unsigned)qy) << tab.sh) | (unsigned)qx;
+    d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell + (unsigned)table_off, 0, 0);
+    j = max((int)__builtin_fmaf((float)d, inv_s, c0), 1);
     *cell_out = (int)cell;
-    return 1;
+    // one decision per sample: hit / go on / end
+    const bool hit = ok & (d == 0);
+    const bool go = ok & (d != 0) & (j < steps);
+    if (!go) return hit ? 1 : 2;
+  } else {
+    const int qx = M::cell(p.x * (float)o.voxelRes[0]);
+    const int qy = M::cell(p.y * (float)o.voxelRes[1]);
+    const int qz = M::cell(p.z * (float)o.voxelRes[2]);
+    if (!(in_grid_of(o, qx, qy, qz) & (steps > 0))) return 2;  // renderer.cl:219, :221
+    // (qz*ry + qy)*rx + qx with 24-bit multiplies (full rate; the host only enables the
+    // derived structures when ry*rz < 2^24 and rx < 2^24); the table offset is 64-bit
+    if (LAYOUT == 1) {
+      const unsigned nbx = ((unsigned)o.voxelRes[0] + 7u) >> 3, nby = ((unsigned)o.voxelRes[1] + 3u) >> 2;
+      const unsigned brick = __umul24(__umul24((unsigned)qz >> 2, nby) + ((unsigned)qy >> 2), nbx) + ((unsigned)qx >> 3);
+      const unsigned within = ((((unsigned)qz & 3u) << 2 | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
+      cell = 0;
+      // (64-bit: the bricks of a 1024^3 table alone are 1 GiB; 9 tables follow each other)
+      d = tab.dist8[(((unsigned long long)brick << 7) | within) + table_off];
+    } else {
+      cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy,
+                      (unsigned)o.voxelRes[0]) + (unsigned)qx;
+      d = tab.dist8[cell + table_off];
+    }
+    if (d == 0) {
+      if (LAYOUT == 1)  // surf32 stays row-major
+        cell = __umul24(__umul24((unsigned)qz, (unsigned)o.voxelRes[1]) + (unsigned)qy, (unsigned)o.voxelRes[0]) +
+               (unsigned)qx;
+      *cell_out = (int)cell;
+      return 1;
+    }
+    j = max((int)__builtin_fmaf((float)d, inv_s, c0), 1);
+    if (j >= steps) return 2;  // no sample left that could hit anything
   }
-  // (the floor argument above needs p >= 0; tiny p also means tiny binades)
-  const bool roomy = fminf(fminf(p.x, p.y), p.z) >= 0.015625f;
-  int j = roomy ? 1 + (int)((float)(d - 1) * inv_s) : 1;
-  if (j >= steps) return 2;  // no sample left that could hit anything
   // skip = the reference's own adds (renderer.cl:233) without the fetches.  (A closed
   // form p + j*D, exact while p stays inside one binade, was measured slower: three
   // adds per skipped sample are cheaper than its bookkeeping and failure path.)
@@ -207,30 +214,13 @@ RM_DEV int walk_step(const RmOpts& o, const uint8_t* __restrict__ dist8, v3& p, 
   return 0;
 }
 
-// Two exact instruction-count reductions of the per-estimate set-up.  On the build
-// before the wave-shared AO/shadow phases they measured slower (10.95 ms without, 10.98 /
-// 11.10 / 11.16 ms with the first / second / both: register pressure); with the shared
-// phases 8.87 ms without, 8.78 / 8.89 / 8.73 ms.  Switchable for re-measuring
-// (tools/ab_build.py).
-#ifndef RM_FASTDIV
-#define RM_FASTDIV 1      // per-walk delta = dir/sf via rmd::div_by instead of three divisions
-#endif
-#ifndef RM_LAZY_NORMAL
-#define RM_LAZY_NORMAL 1  // primary / reflection marches: walks reach as far as the ground term; last turn repeated if cut
-#endif
-#ifndef RM_DARK_SKIP
-#define RM_DARK_SKIP 1    // shadow marches whose result is multiplied by exact zeros are not traced
-#endif
-#ifndef RM_INSIDE_TEST
-#define RM_INSIDE_TEST 1  // skip the slab test when the position is inside the box by a margin
-#endif
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
 // come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
 // M: the arithmetic contract (rm_math.hpp) -- MathX86<0> OpenCL CPU device, MathX86<1> the same
 // with the GPU lowering of the seed casts, MathX86<2> cast lowering chosen at run time by
 // Scene::seed_cast_gpu (single-pass parity kernels; the frame kernel is instantiated per mode so
 // that the flag costs its hot code nothing), MathOcl: ROCm's OpenCL library on this GPU
-template <bool COUNT, bool ACCEL = false, bool SDFM = false, bool BRICK = false, class M = MathX86<2>>
+template <bool COUNT, bool ACCEL = false, bool SDFM = false, int LAYOUT = 0, class M = MathX86<2>>
 struct Tracer {
   // the reference's built-ins under the contract (unqualified calls below resolve to these)
   RM_DEV static float dot(v3 a, v3 b) { return M::dot(a, b); }
@@ -252,54 +242,17 @@ struct Tracer {
   // Wave-shared scratch in LDS (kWaveLdsFloats floats of ONE wavefront), or nullptr: lets the
   // lanes of a wavefront hand AO probes and shadow rays to each other (shade_wave()).
   float* lds_ = nullptr;
-#ifdef RM_WORK_STATS
-  // debug build only: what the accelerated path actually executes
-  unsigned int ws_iters = 0, ws_filtered = 0, ws_walks = 0, ws_lookups = 0, ws_jumps = 0, ws_rays = 0,
-               ws_probes = 0, ws_steps = 0;
-  // lane-slots a wavefront spends in a loop (64 per trip, charged to its first active lane)
-  unsigned int wv_walk = 0, wv_filt = 0, wv_est = 0;
-  // split by what the walk belongs to: 0 primary march, 1 reflection march, 2 shadow march, 3 AO probe
-  int ws_kind = 0;
-  unsigned int ws_k_walks[4] = {0, 0, 0, 0}, ws_k_fetch[4] = {0, 0, 0, 0}, ws_k_slots[4] = {0, 0, 0, 0};
-  unsigned int ws_dhist[7] = {0, 0, 0, 0, 0, 0, 0};  // fetched dist8 value: 0 (hit), 1, 2, 3, 4-7, 8+; [6] = last value
-  unsigned int ws_k_nohit[4] = {0, 0, 0, 0}, ws_k_one[4] = {0, 0, 0, 0};  // walks without a hit; of those, ended by their first fetch
-  unsigned int ws_k_est[4] = {0, 0, 0, 0}, ws_k_filt[4] = {0, 0, 0, 0};  // estimate / filtered turns by march kind
-  unsigned int ws_redo = 0;  // marches whose last turn was repeated for its normal
-  unsigned int ws_pairs_skipped = 0;
-  // shadow phases: calls with tasks, rounds as run, rounds if marches without any estimate turn
-  // (the ray never comes near the clip box: filtered turns only) ran in rounds of their own,
-  // tasks, tasks of that cheap kind  [counted by one lane per wavefront]
-  unsigned int ws_sh[6] = {0, 0, 0, 0, 0, 0};
-  unsigned int ws_march_est = 0;  // estimate turns of the last march
-  unsigned int ws_k_follow[4] = {0, 0, 0, 0}, ws_k_follow_ground[4] = {0, 0, 0, 0};
-  unsigned int ws_pairs = 0, ws_pairs_back = 0, ws_pairs_dark = 0;  // (hit, light) pairs; facing away; no specular either
-  unsigned int ws_adds_hit = 0, ws_adds_nohit = 0, ws_adds_lazy = 0;  // samples advanced in walks that hit / do not; of the latter, after the last fetch with value <= 1
-  RM_DEV unsigned int wave_slots() {
-    const unsigned long long act = __ballot(1);
-    return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? 64u : 0u;
+  WalkTab tab_;  // the skip tables as walk_step reads them (uniform)
+  RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {
+    tab_.dist8 = s.dist;
+    tab_.sh = s.log2res;
+    tab_.res = 1u << s.log2res;
+    tab_.fres = (float)(1u << s.log2res);
+    if (LAYOUT == 2) {
+      const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
+      tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
+    }
   }
-#define RM_WS(x) (x)
-#else
-#define RM_WS(x) ((void)0)
-#endif
-#ifdef RM_PHASE_CLOCK
-  // debug build only (-DRM_PHASE_CLOCK, no other instrumentation): wave time per phase of
-  // shade_wave in shader clock ticks, charged to the wave's first active lane:
-  // 0 primary march, 1 reflection marches, 2 AO phases, 3 shadow phases, 4 shading arithmetic
-  // 5 walk loops, 6 estimate set-up (scene_distance up to its walk), 7 hit evaluation, 8 filtered-turn
-  // loops, 9 march set-up (filter, limits), 10 AO task set-up, 11 shadow task set-up, 12 sample + camera
-  unsigned long long ws_clk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  RM_DEV unsigned long long ws_now() {
-    const unsigned long long act = __ballot(1);
-    return ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? (unsigned long long)clock64() : 0ull;
-  }
-#define RM_CLK_T(v) const unsigned long long v = ws_now()
-#define RM_CLK_ADD(k, a, b) do { if ((a) && (b)) ws_clk[k] += (b) - (a); } while (0)
-#else
-#define RM_CLK_T(v) ((void)0)
-#define RM_CLK_ADD(k, a, b) ((void)0)
-#endif
-  RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {}
   RM_DEV void set_pass(const float4* table_of_pass, float time_of_pass) {
     mc_ = table_of_pass;
     time_ = time_of_pass;
@@ -477,7 +430,6 @@ struct Tracer {
       return;
     }
     if (COUNT) cnt.dts_calls++;
-    RM_CLK_T(ck_e0);
     const float h = rpos.y + o.groundY;
     float rd, rc;
     if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
@@ -486,7 +438,7 @@ struct Tracer {
     // all three entry parameters are negative (or -inf), all exits positive, and the
     // reference's slab test returns max(.., 0) = exactly +0 -- without six divisions.
     // (AO probes start on a surface inside the box and almost always qualify.)
-    if (ACCEL && RM_INSIDE_TEST && !known_inside) {
+    if (ACCEL && !known_inside) {
       const float m = 1e-4f;
       known_inside = (rpos.x - o.voxelBoundsMin[0] > m) & (o.voxelBoundsMax[0] - rpos.x > m) &
                      (rpos.y - o.voxelBoundsMin[1] > m) & (o.voxelBoundsMax[1] - rpos.y > m) &
@@ -497,7 +449,7 @@ struct Tracer {
       const float sf = (float)steps * 0.5f;
       const v3 ivs = ld3(o.invVoxelScale);
       v3 delta;
-      if (ACCEL && RM_FASTDIV) {
+      if (ACCEL) {
         const rmd::Divisor by_sf = rmd::make_divisor(sf);
         delta = V(rmd::div_by(dir.x, by_sf), rmd::div_by(dir.y, by_sf), rmd::div_by(dir.z, by_sf)) * ivs;
       } else {
@@ -517,59 +469,21 @@ struct Tracer {
         const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
                               __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
+        const float c0 = 1.0f - inv_s;
         // directional table of this walk (a walk never moves against the signs of delta)
         unsigned long long table_off = 0;  // 64-bit: nine 1024^3 tables span 9 GiB
-        unsigned int coarse_off = 0;
         if (sc.oct_stride) {
           const unsigned int oct = (delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u);
           table_off = (oct + 1u) * sc.oct_stride;
-#if RM_COARSE
-          coarse_off = (oct + 1u) * ((((unsigned)o.voxelRes[0] + 3u) >> 2) * (((unsigned)o.voxelRes[1] + 3u) >> 2) *
-                                     (((unsigned)o.voxelRes[2] + 3u) >> 2));
-#endif
         }
-        (void)coarse_off;
-        RM_WS(ws_walks++);
-        RM_WS(ws_k_walks[ws_kind]++);
         (void)s;
         // the loop holds nothing but the walk: a lane that finds its hit waits for the
         // others and all hits are then evaluated together (inside the loop the compiler
         // runs the hit code once per trip in which any lane finishes)
         int cell = 0, r;
-        RM_CLK_T(ck_w0);
-#ifdef RM_WORK_STATS
-        const int ws_steps0 = steps;
-        int ws_klast = 0;
-        unsigned int ws_nf = 0;
-#endif
         do {
-          RM_WS(ws_lookups++);
-          RM_WS(wv_walk += wave_slots());
-          RM_WS(ws_k_slots[ws_kind] += wave_slots());
-          RM_WS(ws_k_fetch[ws_kind]++);
-          RM_WS(ws_steps += (unsigned)steps);
-          RM_WS(ws_nf++);
-#ifdef RM_WORK_STATS
-          r = walk_step<M, BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, ws_dhist, sc.coarse, coarse_off);
-#else
-          r = walk_step<M, BRICK>(o, sc.dist, p, steps, delta, inv_s, &cell, table_off, nullptr, sc.coarse, coarse_off);
-#endif
-          RM_WS(ws_steps -= (unsigned)steps);
-#ifdef RM_WORK_STATS
-          if (ws_dhist[6] <= 1u && r == 0) ws_klast = ws_steps0 - steps;
-#endif
+          r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off);
         } while (r == 0);
-        RM_CLK_T(ck_w1);
-        RM_CLK_ADD(5, ck_w0, ck_w1);
-#ifdef RM_WORK_STATS
-        if (r == 1) ws_adds_hit += (unsigned)(ws_steps0 - steps);
-        else {
-          ws_adds_nohit += (unsigned)(ws_steps0 - steps);
-          ws_k_nohit[ws_kind]++;
-          if (ws_nf == 1) ws_k_one[ws_kind]++;
-          ws_adds_lazy += (unsigned)(ws_steps0 - steps - ws_klast);
-        }
-#endif
         if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
@@ -578,8 +492,6 @@ struct Tracer {
           const float d = length(rpos - hit) - o.voxelSize;
           if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }
         }
-        RM_CLK_T(ck_w2);
-        RM_CLK_ADD(7, ck_w1, ck_w2);
       } else
       while (--steps >= 0) {
         int qx, qy, qz;
@@ -600,8 +512,6 @@ struct Tracer {
     }
     dist = rd;
     code = rc;
-    RM_CLK_T(ck_e1);
-    RM_CLK_ADD(6, ck_e0, ck_e1);  // (includes 5 and 7: subtracted when printed)
   }
 
   struct Hit { v3 pos, normal; float distance; int objectID; };
@@ -678,10 +588,7 @@ struct Tracer {
                     bool distance_only = false) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
-    RM_WS(ws_rays++);
-    RM_CLK_T(ck_m0);
     float dist = o.startDist;
-    RM_WS(ws_march_est = 0);
     // (the filter reasons about the clip box of the byte grid: off for the counting variant,
     //  which must run the plain algorithm, and for the quality mode, whose field extends
     //  beyond the box)
@@ -712,12 +619,9 @@ struct Tracer {
     const float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
-    RM_CLK_T(ck_m1);
-    RM_CLK_ADD(9, ck_m0, ck_m1);
     for (;;) {
       float g = 0.0f;
       why = 2;
-      RM_CLK_T(ck_f0);
       if (maxSteps > 0) {
         // one exit: a turn either continues (filtered, not converged, turns left) or not
         bool nw, go;
@@ -726,24 +630,15 @@ struct Tracer {
           last_t = dist;
           const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
           g = h < 1e5f ? h : 1e5f;
-          RM_WS(ws_iters++);
-          RM_WS(wv_filt += wave_slots());
           nw = kFilter && surely_no_walk(flt, dist, g);
-          RM_WS(ws_filtered += nw ? 1u : 0u);
-          RM_WS(ws_k_filt[ws_kind] += nw ? 1u : 0u);
           go = nw & !((__builtin_fabsf(g) <= o.eps) | (dist >= maxDist));
           dist = go ? dist + g : dist;
         } while (go & (maxSteps > 0));
         why = go ? 2 : (nw ? 3 : 1);
         if (nw) last_kind = 0;
       }
-      RM_CLK_T(ck_f1);
-      RM_CLK_ADD(8, ck_f0, ck_f1);
       if (why != 1) break;
       float sd;
-      RM_WS(wv_est += wave_slots());
-      RM_WS(ws_k_est[ws_kind]++);
-      RM_WS(ws_march_est++);
       const bool inside = kFilter && surely_inside(flt, dist, g);
       int limit = 0x7fffffff;
       // (`dist` counts in units of |rdir|: the remaining world distance is (maxDist - dist) * |rdir|)
@@ -754,24 +649,17 @@ struct Tracer {
       // the last turn's normal survives, so walk as far as the ground term now and repeat the
       // last turn without limit afterwards if its walk was cut (rare: the last turn of a ray
       // is a filtered one or finds its hit close by)
-      if (ACCEL && RM_LAZY_NORMAL && !distance_only) limit = walk_limit_from(g, spu);
+      if (ACCEL && !distance_only) limit = walk_limit_from(g, spu);
       cut_last = false;
       scene_distance(muladd(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
                      &cut_last);
       last_kind = 1;
-#ifdef RM_WORK_STATS
-      if (ws_march_est >= 2u) {  // not the first real estimate of this march
-        ws_k_follow[ws_kind]++;
-        if (sd == g) ws_k_follow_ground[ws_kind]++;  // ... and it found nothing closer than the ground term
-      }
-#endif
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
       dist += sd;
     }
     if (maxSteps != turns0) {  // at least one turn: renderer.cl:244-246 values of the last one
       r.pos = muladd(rdir, last_t, ro);
-      if (ACCEL && RM_LAZY_NORMAL && !distance_only && last_kind == 1 && cut_last) {
-        RM_WS(ws_redo++);
+      if (ACCEL && !distance_only && last_kind == 1 && cut_last) {
         float sd2, sc2;
         scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
       }
@@ -822,12 +710,7 @@ struct Tracer {
   // renderer.cl:292-301
   RM_DEV float shadow_term(v3 p, v3 ldir, float lmax) {
     Hit h{};
-#ifdef RM_WORK_STATS
-    const int ws_saved = ws_kind;
-    ws_kind = 2;
-#endif
     march(p, ldir, h, lmax, sc.o->shadowIter, false, true);
-    RM_WS(ws_kind = ws_saved);
     return M::step(lmax, h.distance);
   }
   RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) { return schlick_of<M>(r0, smooth, n, view); }
@@ -839,7 +722,6 @@ struct Tracer {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.ao_calls++;
     float ao = 1.0f;
-    RM_WS(ws_probes++);
     float d = 0.0f;
     uint32_t seed =
         seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
@@ -850,14 +732,9 @@ struct Tracer {
       const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, normal));
       float sd, scode;
       v3 nn;
-#ifdef RM_WORK_STATS
-      const int ws_saved = ws_kind;
-      ws_kind = 3;
-#endif
       const v3 rpos = mads(n, d, pos);
       scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false,
                      ACCEL ? ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2) : 0x7fffffff);
-      RM_WS(ws_kind = ws_saved);
       ao *= 1.0f - M::fmax((d - sd) * o.aoAmp / d, 0.0f);
     }
     return ao;
@@ -895,7 +772,6 @@ struct Tracer {
   // one reflection bounce: renderer.cl:383-405
   RM_DEV v3 bounce_colour(const Sample& s, v3 ro, v3 rdir, Hit& h) {
     const RmOpts& o = *sc.o;
-    RM_WS(ws_kind = 1);
     march(ro, rdir, h, o.maxDist, o.maxIter, false);
     v3 col;
     if (h.objectID < 0) {
@@ -910,9 +786,7 @@ struct Tracer {
   RM_DEV v3 sample_colour(const Sample& s, v3 ro, v3 rdir) {
     const RmOpts& o = *sc.o;
     Hit h{};
-    RM_WS(ws_kind = 0);
     march(ro, rdir, h, o.maxDist, o.maxIter, true);
-    RM_WS(ws_kind = 0);
     v3 col;
     if (h.distance >= o.maxDist) {
       col = sky(rdir);
@@ -1030,7 +904,6 @@ struct Tracer {
     const uint32_t seed0 =
         seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
     if (active) {
-      RM_WS(ws_probes++);
       lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
       lds_in(3, dl.lane) = normal.x; lds_in(4, dl.lane) = normal.y; lds_in(5, dl.lane) = normal.z;
       lds_in(6, dl.lane) = __uint_as_float(seed0);
@@ -1041,16 +914,11 @@ struct Tracer {
     }
     wave_sync();
     const int tasks = np * dl.owners;
-#ifdef RM_WORK_STATS
-    const int ws_kind_saved = ws_kind;
-    ws_kind = 3;
-#endif
     for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
       const int t = base + dl.my_slot;
       if (t < tasks) {
         int probe, rank;
         divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
-        RM_CLK_T(ck_a0);
         const int owner = lds_map(rank);
         const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
         const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
@@ -1069,13 +937,10 @@ struct Tracer {
         v3 nn;
         const v3 rpos = mads(n, d, opos);
         const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
-        RM_CLK_T(ck_a1);
-        RM_CLK_ADD(10, ck_a0, ck_a1);
         scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
         lds_res(probe, owner) = sd;
       }
     }
-    RM_WS(ws_kind = ws_kind_saved);
     wave_sync();
     float ao = 1.0f;
     if (active) {
@@ -1091,7 +956,6 @@ struct Tracer {
 
   // the shadow marches of lighting() for all lanes: distance reached by the march towards
   // light i in lds_res(i, lane) (only where the light passes the attenuation test)
-#if RM_DARK_SKIP
   // `need`: bit i set = this lane owns a hit whose light i needs its shadow march (lighting_wave)
   RM_DEV void shadows_wave(unsigned int need, v3 hitpos, v3 jit) {
     const RmOpts& o = *sc.o;
@@ -1113,43 +977,11 @@ struct Tracer {
       tasks += __popcll(mk);
     }
     wave_sync();
-#ifdef RM_WORK_STATS
-    const int ws_kind_saved = ws_kind;
-    ws_kind = 2;
-    int ws_cheap_total = 0;
-#endif
     for (int base = 0; base < tasks; base += dl.helpers) {
       const int t = base + dl.my_slot;
       if (t < tasks) {
-        RM_CLK_T(ck_s0);
         const int e = task_of[t];
         const int light = e >> 6, owner = e & 63;
-        RM_WS(ws_march_est = 1);  // (a task that fails the attenuation test: cannot happen here)
-#else
-  RM_DEV void shadows_wave(bool active, v3 hitpos, v3 jit) {
-    const RmOpts& o = *sc.o;
-    const int nl = o.numLights;
-    const Deal dl = deal(active);
-    if (dl.owners == 0 || nl <= 0) return;
-    if (active) {
-      lds_in(0, dl.lane) = hitpos.x; lds_in(1, dl.lane) = hitpos.y; lds_in(2, dl.lane) = hitpos.z;
-      lds_in(3, dl.lane) = jit.x; lds_in(4, dl.lane) = jit.y; lds_in(5, dl.lane) = jit.z;
-      lds_map(dl.my_rank) = dl.lane;
-    }
-    wave_sync();
-    const int tasks = nl * dl.owners;
-#ifdef RM_WORK_STATS
-    const int ws_kind_saved = ws_kind;
-    ws_kind = 2;
-#endif
-    for (int base = 0; base < tasks; base += dl.helpers) {
-      const int t = base + dl.my_slot;
-      if (t < tasks) {
-        int light, rank;
-        RM_CLK_T(ck_s0);
-        divmod_small(t, dl.owners, light, rank);
-        const int owner = lds_map(rank);
-#endif
         const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
         const v3 ojit = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
         // the expressions of lighting() (renderer.cl:356-362)
@@ -1160,31 +992,11 @@ struct Tracer {
           const v3 ldir = normalize(dlv);
           const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
           Hit h{};
-          RM_CLK_T(ck_s1);
-          RM_CLK_ADD(11, ck_s0, ck_s1);
           march(muladd(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
           lds_res(light, owner) = h.distance;
         }
       }
-#ifdef RM_WORK_STATS
-      {
-        const int cheap = __popcll(__ballot(t < tasks && ws_march_est == 0));
-        if (dl.my_slot == 0) ws_sh[4] += (unsigned)cheap;
-        ws_cheap_total += cheap;
-      }
-#endif
     }
-#ifdef RM_WORK_STATS
-    if (dl.my_slot == 0 && tasks > 0) {
-      ws_sh[0] += 1u;
-      ws_sh[1] += (unsigned)((tasks + dl.helpers - 1) / dl.helpers);
-      const int costly = tasks - ws_cheap_total;
-      ws_sh[2] += (unsigned)((costly + dl.helpers - 1) / dl.helpers);
-      ws_sh[3] += (unsigned)tasks;
-      if (tasks > dl.helpers) ws_sh[5] += 1u;
-    }
-#endif
-    RM_WS(ws_kind = ws_kind_saved);
     wave_sync();
   }
 
@@ -1193,24 +1005,13 @@ struct Tracer {
                           v3 normal, bool mirror_sky, v3 reflectCol) {
     const RmOpts& o = *sc.o;
     if (__ballot(active) == 0) return V(0.f, 0.f, 0.f);  // uniform
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c0 = ws_now();
-#endif
     const float ao = occlusion_wave(active, s, hitpos, normal);
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c1 = ws_now();
-    if (ws_c0 && ws_c1) ws_clk[2] += ws_c1 - ws_c0;
-#endif
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
       const float4 r = table(seed_of(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
       jit = V(r.x, r.y, r.z);
     }
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c2 = ws_now();
-#endif
-#if RM_DARK_SKIP
     // Which (hit, light) pairs need their shadow march at all.  A pair whose diffuse and
     // specular factors are both exactly +0 (the light is behind the surface: max(0, l.n) = 0,
     // and the half vector too, so blinn_phong takes its `return 0`) adds lightColor*sh*att * 0
@@ -1240,16 +1041,8 @@ struct Tracer {
         }
       }
       if (clean) need &= ~dark;
-      RM_WS(ws_pairs_skipped += (unsigned)__builtin_popcount(clean ? dark : 0u));
     }
     shadows_wave(need, hitpos, jit);
-#else
-    shadows_wave(active, hitpos, jit);
-#endif
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c3 = ws_now();
-    if (ws_c2 && ws_c3) ws_clk[3] += ws_c3 - ws_c2;
-#endif
     v3 res = V(0.f, 0.f, 0.f);
     if (active) {
       const Material m = material(objectID);
@@ -1267,13 +1060,6 @@ struct Tracer {
           const v3 ldir = normalize(dl);
           const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
           const float sh = M::step(lmax, lds_res(i, lane));
-#ifdef RM_WORK_STATS
-          ws_pairs++;
-          if (M::fmax(0.0f, dot(ldir, normal)) == 0.0f) {
-            ws_pairs_back++;
-            if (blinn_phong(m.smoothness, raydir, ldir, normal) == 0.0f) ws_pairs_dark++;
-          }
-#endif
           if (sh > 0.0f) {
             const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
             diff = diff + inc * M::fmax(0.0f, dot(ldir, normal));
@@ -1287,10 +1073,6 @@ struct Tracer {
       res = V(out.x / fl, out.y / fl, out.z / fl);
     }
     wave_sync();  // results consumed before the next shared phase posts
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_c4 = ws_now();
-    if (ws_c3 && ws_c4) ws_clk[4] += ws_c4 - ws_c3;
-#endif
     return res;
   }
 
@@ -1300,14 +1082,7 @@ struct Tracer {
   RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
     const RmOpts& o = *sc.o;
     Hit h{};
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_p0 = ws_now();
-#endif
     if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
-#ifdef RM_PHASE_CLOCK
-    const unsigned long long ws_p1 = ws_now();
-    if (ws_p0 && ws_p1) ws_clk[0] += ws_p1 - ws_p0;
-#endif
     const bool hit = live && !(h.distance >= o.maxDist);
     v3 norm = V(0.f, 0.f, 0.f);
     float r0 = 0.0f;
@@ -1328,20 +1103,11 @@ struct Tracer {
       for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
         if (__ballot(alive) == 0) break;         // uniform
         v3 from = V(0.f, 0.f, 0.f);
-#ifdef RM_PHASE_CLOCK
-        const unsigned long long ws_b0 = ws_now();
-#endif
         if (alive) {
           dir = reflect(dir, rh.normal);
           from = muladd(dir, 0.0075f, rh.pos);
-          RM_WS(ws_kind = 1);
           march(from, dir, rh, o.maxDist, o.maxIter, false);  // bounce_colour(), renderer.cl:383-405
-          RM_WS(ws_kind = 0);
         }
-#ifdef RM_PHASE_CLOCK
-        const unsigned long long ws_b1 = ws_now();
-        if (ws_b0 && ws_b1) ws_clk[1] += ws_b1 - ws_b0;
-#endif
         const bool bhit = alive && rh.objectID >= 0;
         const v3 lit = lighting_wave(bhit, s, dir, rh.pos, rh.objectID, rh.normal, true, V(0.f, 0.f, 0.f));
         if (alive) {
@@ -1362,11 +1128,8 @@ struct Tracer {
   // must call it (lanes without one have left the kernel), lds = kWaveLdsFloats floats
   RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
     lds_ = lds;
-    RM_CLK_T(ck_c0);
     const Sample s = sample_init(id);
     const v3 rdir = camera_dir(s);
-    RM_CLK_T(ck_c1);
-    RM_CLK_ADD(12, ck_c0, ck_c1);
     return sample_colour_wave(s, s.eye, rdir, live) * sc.o->exposure;
   }
 

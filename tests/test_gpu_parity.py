@@ -213,11 +213,11 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
     opts = bytes(opts)
     want, want_argb = oracle_mod.render_frame(sc["vox"], opts, sc["mc"], n)
     for env in ({}, {"RAYMARCH_PASS_PACK": "0"}, {"RAYMARCH_PASS_PACK": "1"}, {"RAYMARCH_PASS_PACK": "6"},
-                {"RAYMARCH_WAVES_PER_SIMD": "4"}, {"RAYMARCH_WAVES_PER_SIMD": "5"}, {"RAYMARCH_WAVES_PER_SIMD": "8"},
+                {"RAYMARCH_POW2": "0"}, {"RAYMARCH_POW2": "0", "RAYMARCH_OCTANTS": "0"},
                 {"RAYMARCH_NO_ACCEL": "1"}, {"RAYMARCH_OCTANTS": "0"}, {"RAYMARCH_XCD_ROWS": "0"},
                 {"RAYMARCH_OCTANTS": "0", "RAYMARCH_PASS_PACK": "0"}, {"RAYMARCH_BRICKS": "1"},
                 {"RAYMARCH_BRICKS": "1", "RAYMARCH_PASS_PACK": "0"}, {"RAYMARCH_PACK_WASTE": "0"}):
-        for k in ("RAYMARCH_NO_ACCEL", "RAYMARCH_WAVES_PER_SIMD", "RAYMARCH_PASS_PACK", "RAYMARCH_OCTANTS",
+        for k in ("RAYMARCH_NO_ACCEL", "RAYMARCH_POW2", "RAYMARCH_PASS_PACK", "RAYMARCH_OCTANTS",
                   "RAYMARCH_XCD_ROWS", "RAYMARCH_BRICKS", "RAYMARCH_PACK_WASTE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

@@ -1,7 +1,10 @@
 """The claim the accelerated walk rests on, checked directly (not through pixels): whenever the
-kernel's walk_step fetches the table value d at a sample and advances j = 1 + floor(0.98 (d-1) / s)
-samples at once (rm_shade.hpp), the j-1 samples it does not look at lie in empty cells inside the
-grid -- so the reference, which fetches every sample, would neither hit nor stop there.
+kernel's walk_step fetches the table value d at a sample and advances
+j = max(1, floor(d * inv_s + (1 - inv_s))) = 1 + floor(0.98 (d-1) / s) samples at once
+(rm_shade.hpp; one fma), the j-1 samples it does not look at lie in empty cells inside the grid --
+so the reference, which fetches every sample, would neither hit nor stop there.  No condition on
+the position: starts include coordinates slightly below 0, which the reference truncates to cell 0
+(renderer.cl:165) -- a face cell, whose table value is 1 whenever the walk heads outward.
 
 The tables come from the device (dist8 and the eight directional tables of the resident volume);
 the walk is replayed on the host in float32 with the reference's sequential position adds, for
@@ -63,8 +66,9 @@ def test_skipped_samples_are_empty_and_in_grid(gpu_ctx, kind, res, iso, rays):
         ended = dv == 0
         alive[idx[ended]] = False
         idx, dv = idx[~ended], dv[~ended]
-        roomy = p[idx].min(axis=1) >= F(0.015625)
-        j = np.where(roomy, 1 + ((dv - 1).astype(F) * inv_s[idx]).astype(np.int32), 1)
+        # the device's single-rounding fma, taken a rounding step larger
+        v = dv.astype(np.float64) * inv_s[idx].astype(np.float64) + (F(1.0) - inv_s[idx]).astype(np.float64)
+        j = np.maximum(np.floor(v * (1 + 2.0 ** -22) + 2.0 ** -20).astype(np.int64), 1).astype(np.int32)
         done = j >= steps[idx]
         alive[idx[done]] = False
         idx, j = idx[~done], j[~done]

@@ -2,7 +2,7 @@
 # Everything profiles/ holds for the current build, in one GPU call:
 #   kernel trace (rocprofv3 --kernel-trace --stats), the PMC passes, the traffic json (with the
 #   digest of the sources), the default bench line, the other workloads, the tile-partition
-#   timing, work statistics and the phase clock.  Output -> gpurun_out/final/
+#   timing.  Output -> gpurun_out/final/
 # (bench.py runs strictly serial frames under the profilers so that per-launch numbers are those
 #  of one launch; the bench line itself uses the default frames in flight.)
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -29,13 +29,11 @@ j = json.load(open(p))
 j["source_digest"] = bench.source_digest()
 json.dump(j, open(p, "w"), indent=1)
 # the bench line below reads it from profiles/
-json.dump(j, open(os.path.join(R, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(j, open(os.path.join(R, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
 PY
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 for w in c1 c3 c4 c5; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1; done > $OUT/other_workloads.txt
 python tools/part_timing.py --frames-in-flight 2 --reps 30 > $OUT/part_timing.txt 2>&1
-python tools/work_stats.py c2 > $OUT/work_stats.txt 2>&1
-python tools/work_stats.py c2 --clock >> $OUT/work_stats.txt 2>&1
 python tools/sdf_bench.py > $OUT/sdf_bench.txt 2>&1
 rm -rf $OUT/pmc/p*/pmc_results.db
 head -c 700 $OUT/bench_line.json; echo; tail -3 $OUT/part_timing.txt; head -6 $OUT/kernel_stats.txt
