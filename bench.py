@@ -137,7 +137,7 @@ def main():
                     help="ranks: one process per GPU, torch.distributed (RCCL) gather of the tile accumulators; "
                          "library: ONE process, the frame tiled over N devices inside the C library "
                          "(rm_create_multi: peer copies over xGMI, no RCCL) -- what a JNI caller gets")
-    ap.add_argument("--contract", default="cpu", choices=["cpu", "gfx950"],
+    ap.add_argument("--contract", default="gfx950", choices=["cpu", "gfx950"],
                     help="arithmetic contract of the kernels (include/raymarch_hip.h rm_set_contract): cpu = the "
                          "results of an OpenCL CPU device (checked against the CPU oracle), gfx950 = the results of "
                          "the reference kernel built by ROCm's OpenCL compiler for this GPU (checked against that "
@@ -309,6 +309,19 @@ def main():
             out["host_boundary"] = {"ms_per_frame": round(host_ms, 3),
                                     "Mrays_per_s": round(samples_per_frame / host_ms / 1e3, 2),
                                     "note": "rm_render_frame with host buffers (PCIe-inclusive)"}
+        if world == 1:
+            # the other arithmetic contract, same frame, strictly serial (reported, never `value`)
+            other = "cpu" if args.contract == "gfx950" else "gfx950"
+            fo = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, device=dev, frames_in_flight=1, contract=other)
+            oms = []
+            for _ in range(6):
+                fo.render()
+                torch.cuda.synchronize(dev)
+                oms.append(fo.ctx.last_frame_timing()[0])
+            fo.close()
+            out["other_contract"] = {"contract": other, "kernel_ms": round(float(np.median(oms[1:])), 4),
+                                     "note": "both contracts are parity-checked bit for bit, each against its own "
+                                             "reference build (tests/test_gpu_device_contract.py, test_gpu_configs.py)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vox, opts, mc, n, spp, args.cpu_passes)
     if rank == 0:
@@ -459,6 +472,17 @@ def cpu_baseline(vox, opts, mc, n, spp, passes):
                     "are out-of-line calls into a shim.  PREBUILT in the build container (oracle/_ref is "
                     "git-ignored and travels with the snapshot): a clean clone without /root/reference "
                     "reports only the port"}
+    except Exception:
+        pass
+    try:  # the reference kernel itself on THIS GPU (prebuilt code object of the unmodified renderer.cl)
+        if oracle.have_gfx950_ref("fast"):
+            _px, _argb, ms = oracle.gfx950_render_frame(vox, opts[:passes * 544], mc[:passes], n, build="fast", tonemap=False)
+            _px, _argb, ms = oracle.gfx950_render_frame(vox, opts[:passes * 544], mc[:passes], n, build="fast", tonemap=False)
+            out["reference_kernel_on_this_gpu"] = {
+                "value": round(n * passes / ms / 1e3, 2), "unit": "Mrays/s", "ms_per_pass": round(ms / passes, 3),
+                "note": "RenderImage of the unmodified renderer.cl built by ROCm's OpenCL compiler for gfx950 with the "
+                        "reference's own options (-cl-fast-relaxed-math -cl-mad-enable, core.clj:128), one launch per "
+                        "pass, device time of the same sample; prebuilt in the build container (oracle/_ref)"}
     except Exception:
         pass
     return out

@@ -8,6 +8,10 @@
 ;; init-renderer, make-render-option-buffer, update-render-option-buffer, test-render and
 ;; test-anim keep the reference's names and parameter lists (core.clj:99-213).
 ;;
+;; No OpenCL is touched at run time: volumes are read by the library (Native/voxInfo, Native/voxLoad)
+;; -- the reference's vio/load-volume wraps the bytes into a simplecl buffer and needs a bound OpenCL
+;; state (io.clj:28-33), the very thing this namespace replaces.
+;;
 ;; UNVERIFIED HERE: the build image has no JVM.  tests/test_jni_shim.py checks statically that
 ;; the parameter lists match the reference's and that only declared natives are called; the JNI
 ;; shim itself is compiled and run from C on the GPU.
@@ -15,7 +19,6 @@
   (:require
    [thi.ng.raymarchcl.core :as core]
    [thi.ng.raymarchcl.generators :as gen]
-   [thi.ng.raymarchcl.io :as vio]
    [thi.ng.structgen.core :as sg]
    [thi.ng.math.core :as m]
    [piksel.core :as pix])
@@ -65,11 +68,17 @@
       (.put ^FloatBuffer fb (float-array (gen/generate-scatter-offsets 0x4000))))
     buf))
 
-(defn- as-direct
-  ^ByteBuffer [^ByteBuffer b]
-  (if (.isDirect b)
-    b
-    (doto (direct (.remaining b)) (.put (.duplicate b)) (.rewind))))
+(defn load-volume
+  "A .vox file (io.clj:9-33: \"VOXEL\", three big-endian ints, element size, bytes) -> {:res [rx ry rz]
+  :voxels direct-buffer}, read by the library -- no OpenCL buffer is involved."
+  [path]
+  (let [hdr (direct 12)]
+    (Native/voxInfo path hdr)
+    (let [res (mapv #(.getInt hdr (* 4 %)) (range 3))
+          n   (long (reduce * res))
+          buf (direct n)]
+      (Native/voxLoad path buf n)
+      {:res res :voxels buf})))
 
 (defn- open-device
   "One GPU, or -- with :devices n in the renderer args -- the first n GPUs of the node sharing
@@ -83,10 +92,12 @@
 
 (defn init-renderer
   [{:keys [width height vres iter vname] :as args}]
-  (let [[rx ry rz] (if (number? vres) [vres vres vres] vres)
+  (let [{:keys [res voxels]} (load-volume (or vname "gyroid-sliced-512-s0.01.vox"))
+        [rx ry rz] res
         handle     (open-device (get args :devices 1))
         pixels     (* width height)]
-    (Native/setVolume handle (as-direct (vio/load-volume (or vname "gyroid-sliced-512-s0.01.vox"))) rx ry rz)
+    (when-let [c (get args :contract)] (Native/setContract handle (if (= c :gfx950) 1 0)))
+    (Native/setVolume handle voxels rx ry rz)
     {:handle       handle
      :num          pixels
      :iter         iter

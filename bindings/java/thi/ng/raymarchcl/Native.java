@@ -4,9 +4,12 @@ import java.nio.ByteBuffer;
 
 /**
  * Static native methods of the JNI shim (bindings/jni/raymarch_jni.c) over libraymarch_hip.so.
- * Unverified in the build image (no JDK); every buffer must be a DIRECT java.nio buffer in
- * native byte order -- what thi.ng.simplecl passes to JOCL in the reference (core.clj:137-145).
- * Non-zero library return codes arrive as RuntimeException with the library's message.
+ * Unverified in the build image (no JDK).  EVERY buffer is a DIRECT java.nio.ByteBuffer in native
+ * byte order (sizes are checked in bytes; use asFloatBuffer()/asIntBuffer() views on the Java side)
+ * -- what thi.ng.simplecl passes to JOCL in the reference (core.clj:137-145).  A null, non-direct
+ * or too small required buffer raises IllegalArgumentException before any native call; outputs
+ * documented as optional may be null.  Non-zero library return codes arrive as RuntimeException
+ * with the library's message.
  */
 public final class Native {
     static { System.loadLibrary("raymarch_jni"); }
@@ -24,4 +27,10 @@ public final class Native {
                                          ByteBuffer pixelsOut, ByteBuffer argbOut);
     public static native float lastFrameMillis(long handle);
     public static native int makeScatterTable(long seed, ByteBuffer out);
+    /** 0: the results of an OpenCL CPU device (default); 1: of the reference kernel built for this GPU. */
+    public static native int setContract(long handle, int contract);
+    /** Header of a .vox file (io.clj:9-33): out3 receives rx, ry, rz (3 ints). */
+    public static native int voxInfo(String path, ByteBuffer out3);
+    /** The volume bytes of a .vox file into voxelsOut (capacity = rx*ry*rz from voxInfo). */
+    public static native int voxLoad(String path, ByteBuffer voxelsOut, long capacity);
 }

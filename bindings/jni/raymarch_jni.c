@@ -32,16 +32,26 @@ static jint check(JNIEnv* env, int rc) {
   }
   return rc;
 }
-/* a direct buffer that must hold at least `bytes`; throws and returns NULL otherwise */
+static void* throw_iae(JNIEnv* env, const char* what) {
+  jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+  if (ex) (*env)->ThrowNew(env, ex, what);
+  return NULL;
+}
+/* A REQUIRED direct ByteBuffer that must hold at least `bytes` (every buffer of Native.java is a
+ * ByteBuffer: GetDirectBufferCapacity counts elements of the buffer's own type).  Null, not direct
+ * or too small: IllegalArgumentException, NULL returned, no native call is made. */
 static void* addr_of(JNIEnv* env, jobject buf, jlong bytes, const char* what) {
-  if (!buf) return NULL;
+  if (!buf) return throw_iae(env, what);
   void* p = (*env)->GetDirectBufferAddress(env, buf);
   const jlong cap = (*env)->GetDirectBufferCapacity(env, buf);
-  if (!p || cap < bytes) {
-    jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
-    if (ex) (*env)->ThrowNew(env, ex, what);
-    return NULL;
-  }
+  if (!p || cap < bytes) return throw_iae(env, what);
+  return p;
+}
+/* an OPTIONAL output buffer: null is allowed (*absent = 1), anything else is checked as above */
+static void* opt_addr_of(JNIEnv* env, jobject buf, jlong bytes, const char* what, int* bad) {
+  if (!buf) return NULL;
+  void* p = addr_of(env, buf, bytes, what);
+  if (!p) *bad = 1;
   return p;
 }
 #define CTX(h) ((rm_ctx*)(intptr_t)(h))
@@ -58,7 +68,7 @@ JNIEXPORT jlong JNICALL Java_thi_ng_raymarchcl_Native_createMulti(JNIEnv* env, j
                                                                   jint nDevices) {
   rm_ctx* ctx = NULL;
   (void)c;
-  const int* ids = (const int*)addr_of(env, deviceIds, (jlong)nDevices * 4, "deviceIds: direct IntBuffer too small");
+  const int* ids = (const int*)addr_of(env, deviceIds, (jlong)nDevices * 4, "deviceIds: needs a direct ByteBuffer of nDevices ints");
   if (!ids) return 0;
   check(env, rm_create_multi(ids, nDevices, &ctx));
   return (jlong)(intptr_t)ctx;
@@ -83,8 +93,9 @@ JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_setVolume(JNIEnv* env, jcla
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_makeGyroidVolume(JNIEnv* env, jclass c, jlong h, jint rx,
                                                                      jint ry, jint rz, jobject voxelsOut) {
   (void)c;
-  uint8_t* p = (uint8_t*)addr_of(env, voxelsOut, (jlong)rx * ry * rz, "voxelsOut: direct ByteBuffer too small");
-  if (voxelsOut && !p) return RM_EINVAL;
+  int bad = 0;
+  uint8_t* p = (uint8_t*)opt_addr_of(env, voxelsOut, (jlong)rx * ry * rz, "voxelsOut: direct ByteBuffer too small", &bad);
+  if (bad) return RM_EINVAL;
   return check(env, rm_make_gyroid_volume(CTX(h), rx, ry, rz, p));
 }
 /* one RenderImage step of the pipeline (core.clj:84-89) */
@@ -117,9 +128,10 @@ JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_renderFrame(JNIEnv* env, jc
   (void)c;
   const void* po = addr_of(env, optsArray, (jlong)iter * RM_OPTS_BYTES, "optsArray: needs iter x 544 bytes");
   const float* pm = (const float*)addr_of(env, mcArray, (jlong)iter * RM_TABLE_FLOATS * 4, "mcArray: needs iter tables");
-  float* pp = (float*)addr_of(env, pixelsOut, (jlong)n * 16, "pixelsOut: needs n float4");
-  uint32_t* pa = (uint32_t*)addr_of(env, argbOut, (jlong)n * 4, "argbOut: needs n ints");
-  if (!po || !pm || (pixelsOut && !pp) || (argbOut && !pa)) return RM_EINVAL;
+  int bad = 0;
+  float* pp = (float*)opt_addr_of(env, pixelsOut, (jlong)n * 16, "pixelsOut: needs n float4", &bad);
+  uint32_t* pa = (uint32_t*)opt_addr_of(env, argbOut, (jlong)n * 4, "argbOut: needs n ints", &bad);
+  if (!po || !pm || bad) return RM_EINVAL;
   return check(env, rm_render_frame(CTX(h), po, pm, iter, n, pp, pa));
 }
 /* device time of the render kernel(s) of the last frame, in milliseconds (< 0: none yet) */
@@ -136,4 +148,36 @@ JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_makeScatterTable(JNIEnv* en
   float* p = (float*)addr_of(env, out, (jlong)RM_TABLE_FLOATS * 4, "out: needs 0x4000 float4");
   if (!p) return RM_EINVAL;
   return check(env, rm_make_scatter_table((uint64_t)seed, p));
+}
+
+/* whose results the kernels reproduce: 0 = an OpenCL CPU device (default), 1 = the reference
+ * kernel as ROCm's OpenCL compiler builds it for this GPU (rm_set_contract) */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_setContract(JNIEnv* env, jclass c, jlong h, jint contract) {
+  (void)c;
+  return check(env, rm_set_contract(CTX(h), contract));
+}
+/* vio/load-volume (io.clj:19-33) without OpenCL: header of a .vox file -> out = {rx, ry, rz} (3 ints) */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_voxInfo(JNIEnv* env, jclass c, jstring path, jobject out3) {
+  (void)c;
+  int* o = (int*)addr_of(env, out3, 12, "out: needs 3 ints");
+  if (!o) return RM_EINVAL;
+  if (!path) { throw_iae(env, "path is null"); return RM_EINVAL; }
+  const char* p = (*env)->GetStringUTFChars(env, path, NULL);
+  if (!p) return RM_EINVAL;
+  const int rc = rm_vox_info(p, &o[0], &o[1], &o[2]);
+  (*env)->ReleaseStringUTFChars(env, path, p);
+  return check(env, rc);
+}
+/* ... and its bytes into a direct buffer of at least rx*ry*rz bytes */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_voxLoad(JNIEnv* env, jclass c, jstring path, jobject voxelsOut,
+                                                            jlong capacity) {
+  (void)c;
+  uint8_t* o = (uint8_t*)addr_of(env, voxelsOut, capacity, "voxelsOut: direct ByteBuffer smaller than `capacity`");
+  if (!o) return RM_EINVAL;
+  if (!path) { throw_iae(env, "path is null"); return RM_EINVAL; }
+  const char* p = (*env)->GetStringUTFChars(env, path, NULL);
+  if (!p) return RM_EINVAL;
+  const int rc = rm_vox_load(p, o, (size_t)capacity);
+  (*env)->ReleaseStringUTFChars(env, path, p);
+  return check(env, rc);
 }

@@ -7,7 +7,7 @@
  * scene.bin: int32 rx, ry, rz, iter, n, then rx*ry*rz voxel bytes, iter*544 option bytes,
  * iter*0x4000*4 floats.  out.bin: n float4 + n ARGB words of Native.renderFrame, then the same
  * from the single-pass entry points (renderImage per pass + tonemapImage), then one int32 per
- * error-path check (1 = the expected Java exception was raised).
+ * check (1 = passed: expected Java exceptions raised, helpers equal to the C ABI, .vox round trip).
  */
 #include <jni.h>
 #include <stdio.h>
@@ -38,6 +38,15 @@ static jint t_ThrowNew(JNIEnv* env, jclass clazz, const char* msg) {
 }
 static void* t_Addr(JNIEnv* env, jobject b) { (void)env; return b->addr; }
 static jlong t_Cap(JNIEnv* env, jobject b) { (void)env; return b->cap; }
+/* a java.lang.String to the shim: the stand-in object carries the UTF-8 bytes in `addr` */
+static int g_strings_out = 0;
+static const char* t_GetUTF(JNIEnv* env, jstring s, jboolean* is_copy) {
+  (void)env;
+  if (is_copy) *is_copy = 0;
+  g_strings_out++;
+  return (const char*)s->addr;
+}
+static void t_ReleaseUTF(JNIEnv* env, jstring s, const char* chars) { (void)env; (void)s; (void)chars; g_strings_out--; }
 
 /* the shim's exports */
 jlong Java_thi_ng_raymarchcl_Native_create(JNIEnv*, jclass, jint);
@@ -51,6 +60,9 @@ jint Java_thi_ng_raymarchcl_Native_tonemapImage(JNIEnv*, jclass, jlong, jobject,
 jint Java_thi_ng_raymarchcl_Native_renderFrame(JNIEnv*, jclass, jlong, jobject, jobject, jint, jint, jobject, jobject);
 jfloat Java_thi_ng_raymarchcl_Native_lastFrameMillis(JNIEnv*, jclass, jlong);
 jint Java_thi_ng_raymarchcl_Native_makeScatterTable(JNIEnv*, jclass, jlong, jobject);
+jint Java_thi_ng_raymarchcl_Native_setContract(JNIEnv*, jclass, jlong, jint);
+jint Java_thi_ng_raymarchcl_Native_voxInfo(JNIEnv*, jclass, jstring, jobject);
+jint Java_thi_ng_raymarchcl_Native_voxLoad(JNIEnv*, jclass, jstring, jobject, jlong);
 
 static struct rm_test_jobject_ buf(void* p, size_t bytes) {
   struct rm_test_jobject_ b = {p, (jlong)bytes, NULL};
@@ -59,7 +71,7 @@ static struct rm_test_jobject_ buf(void* p, size_t bytes) {
 
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
-  const struct JNINativeInterface_ table = {t_FindClass, t_ThrowNew, t_Addr, t_Cap};
+  const struct JNINativeInterface_ table = {t_FindClass, t_ThrowNew, t_Addr, t_Cap, t_GetUTF, t_ReleaseUTF};
   JNIEnv envp = &table;
   JNIEnv* env = &envp;
   FILE* f = fopen(argv[1], "rb");
@@ -77,7 +89,7 @@ int main(int argc, char** argv) {
   uint32_t* argb = calloc(n, 4);
   float* px1 = calloc((size_t)n * 4, 4);
   uint32_t* argb1 = calloc(n, 4);
-  int32_t checks[6] = {0, 0, 0, 0, 0, 0};
+  int32_t checks[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   if (Java_thi_ng_raymarchcl_Native_deviceCount(env, NULL) < 1) return 4;
   const jlong h = Java_thi_ng_raymarchcl_Native_create(env, NULL, 0);
@@ -148,6 +160,38 @@ int main(int argc, char** argv) {
     free(g);
     free(g2);
   }
+  /* a null REQUIRED buffer -> IllegalArgumentException (no silent error code), optional outputs may be null */
+  g_throws = 0;
+  Java_thi_ng_raymarchcl_Native_renderFrame(env, NULL, h, NULL, &bmc, iter, n, &bpx, &bargb);
+  checks[6] = g_throws == 1 && strcmp(g_thrown_class, "java/lang/IllegalArgumentException") == 0;
+  g_throws = 0;
+  checks[6] = checks[6] && Java_thi_ng_raymarchcl_Native_renderFrame(env, NULL, h, &bopts, &bmc, iter, n, NULL, &bargb) == 0 &&
+              g_throws == 0;
+  /* .vox through the shim: written by the C ABI, header and bytes read back by voxInfo / voxLoad */
+  {
+    char path[512];
+    snprintf(path, sizeof path, "%s.vox", argv[2]);
+    int32_t res3[3] = {0, 0, 0};
+    uint8_t* back = malloc(nvox);
+    struct rm_test_jobject_ spath = {path, (jlong)strlen(path), NULL}, bres = buf(res3, 12), bback = buf(back, nvox);
+    g_throws = 0;
+    checks[7] = rm_vox_save(path, rx, ry, rz, vox) == 0 &&
+                Java_thi_ng_raymarchcl_Native_voxInfo(env, NULL, &spath, &bres) == 0 && res3[0] == rx && res3[1] == ry &&
+                res3[2] == rz && Java_thi_ng_raymarchcl_Native_voxLoad(env, NULL, &spath, &bback, (jlong)nvox) == 0 &&
+                memcmp(back, vox, nvox) == 0 && g_throws == 0 && g_strings_out == 0;
+    /* a missing file -> RuntimeException with the library's message */
+    struct rm_test_jobject_ nopath = {"/nonexistent/x.vox", 18, NULL};
+    Java_thi_ng_raymarchcl_Native_voxInfo(env, NULL, &nopath, &bres);
+    checks[7] = checks[7] && g_throws == 1 && strcmp(g_thrown_class, "java/lang/RuntimeException") == 0;
+    remove(path);
+    free(back);
+  }
+  /* the arithmetic contract through the shim: accepted values, a bad value raises */
+  g_throws = 0;
+  checks[8] = Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 1) == 0 &&
+              Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 0) == 0 && g_throws == 0;
+  Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 7);
+  checks[8] = checks[8] && g_throws == 1;
   Java_thi_ng_raymarchcl_Native_destroy(env, NULL, h);
   f = fopen(argv[2], "wb");
   if (!f) return 9;
@@ -155,7 +199,7 @@ int main(int argc, char** argv) {
   fwrite(argb, 4, n, f);
   fwrite(px1, 4, (size_t)n * 4, f);
   fwrite(argb1, 4, n, f);
-  fwrite(checks, 4, 6, f);
+  fwrite(checks, 4, 9, f);
   fclose(f);
   return 0;
 }

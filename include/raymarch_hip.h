@@ -169,7 +169,10 @@ int rm_tonemap_image(rm_ctx* ctx, const float* pixels, const void* opts544, uint
 /* ops/execute-pipeline of the pipeline built by make-pipeline (core.clj:76-97,
  * 171): accumulator zeroed, `iter` RenderImage passes in order with
  * (opts_i, mc_i), TonemapImage with opts_0, read back.  pixels_out (n float4)
- * and argb_out (n uint32) may each be NULL. */
+ * and argb_out (n uint32) may each be NULL.  Host buffers of 1 MiB or more that a
+ * caller passes AGAIN (same address and size: a JNI caller's direct buffers) are
+ * page-locked with hipHostRegister on that second use, so that later frames move
+ * them by DMA; they stay registered until rm_destroy -- free them after it. */
 int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, int iter, int n,
                     float* pixels_out, uint32_t* argb_out);
 

@@ -43,6 +43,9 @@ def main(argv=None):
     r.add_argument("--gamma", type=float, default=None)
     r.add_argument("--seed", type=int, default=1000, help="seed of the scatter tables")
     r.add_argument("--device", type=int, default=0)
+    r.add_argument("--contract", default="cpu", choices=["cpu", "gfx950"],
+                   help="whose results the kernels reproduce: an OpenCL CPU device (default) or the reference kernel "
+                        "as ROCm's OpenCL compiler builds it for this GPU (include/raymarch_hip.h rm_set_contract)")
     args = ap.parse_args(argv)
 
     from . import core, generators, vio
@@ -76,7 +79,7 @@ def main(argv=None):
     t0 = time.time()
     core.test_render(width=args.width, height=args.height, iter=args.iter, vres=list(vres), mat=args.mat,
                      theta=args.theta, dist=args.dist, voxels=vox, out_path=args.out, mc_seed=args.seed,
-                     device=args.device, **extra)
+                     device=args.device, contract=args.contract, **extra)
     print(f"{args.out}: {args.width}x{args.height}, {args.iter} spp, {time.time() - t0:.2f} s")
     return 0
 

@@ -50,7 +50,7 @@ def update_render_option_buffer(buffers, opts):
 
 
 def init_renderer(width, height, vres, iter=1, vname=None, voxels=None, mc_seed=1000, device=0,
-                  **args):
+                  contract="cpu", **args):
     """Build the render state: option records, one scatter table per pass, the
     device context with the volume resident in HBM, and the pipeline
     (core.clj:119-148)."""
@@ -64,6 +64,7 @@ def init_renderer(width, height, vres, iter=1, vname=None, voxels=None, mc_seed=
         vres3 = (vres,) * 3 if isinstance(vres, int) else tuple(vres)
         voxels = np.ascontiguousarray(voxels).view(np.uint8).reshape(-1)
     ctx = _native.Context(device)
+    ctx.set_contract(contract)
     ctx.set_volume(voxels, vres3)
     state = {
         "ctx": ctx,
@@ -116,7 +117,7 @@ def save_png(argb, width, height, path):
 def test_render(width=640, height=360, iter=1, vres=256, mat="metal", vname=None,
                 out_path="foo.png", theta=135, dist=2.25, **opts):
     """One frame to a PNG (core.clj:154-179).  Extra keys (dof, fov, gamma,
-    groundY, voxelSize, targetpos, voxels, mc_seed, device) are forwarded."""
+    groundY, voxelSize, targetpos, voxels, mc_seed, device, contract) are forwarded."""
     args = dict(width=width, height=height, vres=vres, iter=iter,
                 eyepos=compute_eyepos(theta, dist, 0.35), targetpos=[0, -0.4, 0], mat=mat,
                 vname=vname)
@@ -146,7 +147,7 @@ def test_anim(width, height, iter, res, mat, vname=None, out_dir="export", frame
         theta = lerp(t, 0, 350)
         frame_args = dict(state["args"], fov=lerp(t, 115, 115), targetpos=[0, lerp(t, -0.15, -0.15), 0],
                           eyepos=compute_eyepos(theta, lerp(t, 2.25, 2.25), lerp(t, 0.44, 0.45)))
-        frame_args = {k: v for k, v in frame_args.items() if k not in ("vname", "voxels", "mc_seed", "device")}
+        frame_args = {k: v for k, v in frame_args.items() if k not in ("vname", "voxels", "mc_seed", "device", "contract")}
         update_render_option_buffer(state["opts-buffers"], frame_args)
         argb = execute_pipeline(make_pipeline(state), final_size=state["num"])
         if out_dir:

@@ -30,7 +30,7 @@ def test_shim_compiles_and_exports_what_native_java_declares(tmp_path):
     subprocess.check_call(["gcc", *CFLAGS, "-c", os.path.join(JNI, "raymarch_jni.c"), "-o", str(obj)])
     syms = subprocess.check_output(["nm", "--defined-only", str(obj)], text=True)
     exported = sorted(m.group(1) for m in re.finditer(r" T Java_thi_ng_raymarchcl_Native_(\w+)", syms))
-    assert exported == _java_natives() and len(exported) >= 11
+    assert exported == _java_natives() and len(exported) >= 14
     # the harness compiles against the same declarations (used by the gpu test)
     subprocess.check_call(["gcc", *CFLAGS, "-c", os.path.join(JNI, "test", "harness.c"), "-o", str(tmp_path / "h.o")])
     # every C-ABI function the shim calls is declared in the product header (-Werror above
@@ -58,6 +58,12 @@ def test_clojure_namespace_keeps_the_reference_entry_points():
         assert re.search(sig, src), sig
     called = set(re.findall(r"Native/(\w+)", src))
     assert called and called <= set(_java_natives())
+    # nothing of the OpenCL glue is reachable from this namespace: no simplecl require, no call into the
+    # reference's io namespace (its load-volume builds a simplecl buffer and needs a bound OpenCL state,
+    # io.clj:28-33); volumes come through the library's own .vox reader
+    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(";"))
+    assert "simplecl" not in code and "raymarchcl.io" not in code and "vio/" not in code
+    assert {"voxInfo", "voxLoad", "setVolume", "renderFrame"} <= called
     assert src.count("(") == src.count(")") and src.count("[") == src.count("]") and src.count("{") == src.count("}")
 
 
@@ -89,4 +95,4 @@ def test_every_entry_point_through_a_stand_in_jnienv(tmp_path, native, oracle_mo
     want, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], n)
     assert np.array_equal(px, want.view(np.uint32)) and np.array_equal(argb, want_argb)
     assert np.array_equal(px1, want.view(np.uint32)) and np.array_equal(argb1, want_argb)
-    assert checks.tolist() == [1, 1, 1, 1, 1, 1], checks.tolist()
+    assert checks.tolist() == [1] * 9, checks.tolist()
