@@ -305,10 +305,23 @@ def main():
             for _ in range(3):
                 hctx.render_frame(opts, mc, n)
             host_ms = (time.perf_counter() - th) / 3 * 1e3
+            # the same with long-lived, page-locked caller buffers (what a JNI caller's direct buffers are)
+            h_mc = np.ascontiguousarray(mc, dtype=np.float32).reshape(-1)
+            h_px, h_argb = np.zeros(4 * n, np.float32), np.zeros(n, np.uint32)
+            for a in (h_mc, h_px, h_argb):
+                hctx.pin_host_buffer(a)
+            hctx.render_frame_into(opts, h_mc, n, h_px, h_argb)
+            th = time.perf_counter()
+            for _ in range(5):
+                hctx.render_frame_into(opts, h_mc, n, h_px, h_argb)
+            pinned_ms = (time.perf_counter() - th) / 5 * 1e3
             hctx.close()
             out["host_boundary"] = {"ms_per_frame": round(host_ms, 3),
                                     "Mrays_per_s": round(samples_per_frame / host_ms / 1e3, 2),
-                                    "note": "rm_render_frame with host buffers (PCIe-inclusive)"}
+                                    "ms_per_frame_pinned": round(pinned_ms, 3),
+                                    "note": "rm_render_frame with host buffers (PCIe-inclusive: 4 MiB of tables up, "
+                                            "18 MB of pixels back); _pinned: the caller's buffers registered with "
+                                            "rm_pin_host_buffer"}
         if world == 1:
             # the other arithmetic contract, same frame, strictly serial (reported, never `value`)
             other = "cpu" if args.contract == "gfx950" else "gfx950"

@@ -98,12 +98,17 @@
         pixels     (* width height)]
     (when-let [c (get args :contract)] (Native/setContract handle (if (= c :gfx950) 1 0)))
     (Native/setVolume handle voxels rx ry rz)
-    {:handle       handle
-     :num          pixels
-     :iter         iter
-     :opts-buffers (make-render-option-buffer iter args)
-     :mc-buffers   (scatter-tables iter)
-     :q-buf        (direct (* 4 pixels))}))
+    (let [mc (scatter-tables iter)
+          q  (direct (* 4 pixels))]
+      ;; allocated once, handed to the library every frame: page-locked for DMA
+      (Native/pin handle mc (.capacity mc))
+      (Native/pin handle q (.capacity q))
+      {:handle       handle
+       :num          pixels
+       :iter         iter
+       :opts-buffers (make-render-option-buffer iter args)
+       :mc-buffers   mc
+       :q-buf        q})))
 
 (defn execute-pipeline
   "The reference's (ops/execute-pipeline (:pipeline state) ...), core.clj:76-97 + :171, as one

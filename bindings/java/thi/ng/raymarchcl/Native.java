@@ -33,4 +33,7 @@ public final class Native {
     public static native int voxInfo(String path, ByteBuffer out3);
     /** The volume bytes of a .vox file into voxelsOut (capacity = rx*ry*rz from voxInfo). */
     public static native int voxLoad(String path, ByteBuffer voxelsOut, long capacity);
+    /** Page-lock a long-lived direct buffer handed to renderFrame every frame (DMA at PCIe speed). */
+    public static native int pin(long handle, ByteBuffer buf, long bytes);
+    public static native int unpin(long handle, ByteBuffer buf);
 }

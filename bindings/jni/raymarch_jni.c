@@ -181,3 +181,18 @@ JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_voxLoad(JNIEnv* env, jclass
   (*env)->ReleaseStringUTFChars(env, path, p);
   return check(env, rc);
 }
+
+/* Page-lock a long-lived direct buffer (capacity bytes) that renderFrame will be given frame after
+ * frame (rm_pin_host_buffer); it must stay reachable until unpin / destroy. */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_pin(JNIEnv* env, jclass c, jlong h, jobject buf, jlong bytes) {
+  (void)c;
+  void* p = addr_of(env, buf, bytes, "buf: direct ByteBuffer smaller than `bytes`");
+  if (!p) return RM_EINVAL;
+  return check(env, rm_pin_host_buffer(CTX(h), p, (size_t)bytes));
+}
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_unpin(JNIEnv* env, jclass c, jlong h, jobject buf) {
+  (void)c;
+  void* p = addr_of(env, buf, 0, "buf: not a direct ByteBuffer");
+  if (!p) return RM_EINVAL;
+  return check(env, rm_unpin_host_buffer(CTX(h), p));
+}

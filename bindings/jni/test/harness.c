@@ -63,6 +63,8 @@ jint Java_thi_ng_raymarchcl_Native_makeScatterTable(JNIEnv*, jclass, jlong, jobj
 jint Java_thi_ng_raymarchcl_Native_setContract(JNIEnv*, jclass, jlong, jint);
 jint Java_thi_ng_raymarchcl_Native_voxInfo(JNIEnv*, jclass, jstring, jobject);
 jint Java_thi_ng_raymarchcl_Native_voxLoad(JNIEnv*, jclass, jstring, jobject, jlong);
+jint Java_thi_ng_raymarchcl_Native_pin(JNIEnv*, jclass, jlong, jobject, jlong);
+jint Java_thi_ng_raymarchcl_Native_unpin(JNIEnv*, jclass, jlong, jobject);
 
 static struct rm_test_jobject_ buf(void* p, size_t bytes) {
   struct rm_test_jobject_ b = {p, (jlong)bytes, NULL};
@@ -160,6 +162,9 @@ int main(int argc, char** argv) {
     free(g);
     free(g2);
   }
+  /* (the gyroid above replaced the resident volume) */
+  g_throws = 0;
+  if (Java_thi_ng_raymarchcl_Native_setVolume(env, NULL, h, &bvox, rx, ry, rz) != 0) return 5;
   /* a null REQUIRED buffer -> IllegalArgumentException (no silent error code), optional outputs may be null */
   g_throws = 0;
   Java_thi_ng_raymarchcl_Native_renderFrame(env, NULL, h, NULL, &bmc, iter, n, &bpx, &bargb);
@@ -185,6 +190,25 @@ int main(int argc, char** argv) {
     checks[7] = checks[7] && g_throws == 1 && strcmp(g_thrown_class, "java/lang/RuntimeException") == 0;
     remove(path);
     free(back);
+  }
+  /* page-locked caller buffers: the same frame through pinned buffers, then unpinned again */
+  g_throws = 0;
+  {
+    float* pxp = calloc((size_t)n * 4, 4);
+    struct rm_test_jobject_ bpp = buf(pxp, (size_t)n * 16);
+    if (!checks[6]) fprintf(stderr, "check 6: null-buffer handling failed (%d throws, %s)\n", g_throws, g_thrown_class);
+    int ok = 1, step = 0;
+#define STEP(x) do { step++; if (ok && !(x)) { ok = 0; fprintf(stderr, "check 6: pin step %d failed: %s\n", step, g_thrown_msg); } } while (0)
+    STEP(Java_thi_ng_raymarchcl_Native_pin(env, NULL, h, &bpp, (jlong)n * 16) == 0);
+    STEP(Java_thi_ng_raymarchcl_Native_pin(env, NULL, h, &bmc, (jlong)nmc * 4) == 0);
+    STEP(Java_thi_ng_raymarchcl_Native_renderFrame(env, NULL, h, &bopts, &bmc, iter, n, &bpp, NULL) == 0);
+    STEP(memcmp(pxp, px, (size_t)n * 16) == 0);
+    STEP(Java_thi_ng_raymarchcl_Native_unpin(env, NULL, h, &bpp) == 0);
+    STEP(Java_thi_ng_raymarchcl_Native_unpin(env, NULL, h, &bmc) == 0);
+    STEP(g_throws == 0);
+#undef STEP
+    checks[6] = checks[6] && ok;
+    free(pxp);
   }
   /* the arithmetic contract through the shim: accepted values, a bad value raises */
   g_throws = 0;

@@ -81,6 +81,12 @@ void rm_destroy(rm_ctx* ctx);
 #define RM_OWN_STREAM ((void*)(intptr_t)-1)
 int rm_set_stream(rm_ctx* ctx, void* hip_stream);
 int rm_synchronize(rm_ctx* ctx);
+/* Page-lock a LONG-LIVED caller buffer (hipHostRegister) that will be handed to the host-buffer
+ * entry points frame after frame -- a JNI caller's direct NIO buffers (core.clj:137-145: the
+ * reference allocates its buffers once in init-renderer).  The buffer must stay allocated until
+ * rm_unpin_host_buffer or rm_destroy. */
+int rm_pin_host_buffer(rm_ctx* ctx, const void* p, size_t bytes);
+int rm_unpin_host_buffer(rm_ctx* ctx, const void* p);
 /* The reference source casts float seed expressions to uint (renderer.cl:267, 334, 471, 472);
  * for negative values (about half of all ambient-occlusion seeds) the cast is undefined and
  * OpenCL devices lower it differently.  RM_SEED_CAST_X86 (default): as an OpenCL CPU device on
@@ -169,10 +175,9 @@ int rm_tonemap_image(rm_ctx* ctx, const float* pixels, const void* opts544, uint
 /* ops/execute-pipeline of the pipeline built by make-pipeline (core.clj:76-97,
  * 171): accumulator zeroed, `iter` RenderImage passes in order with
  * (opts_i, mc_i), TonemapImage with opts_0, read back.  pixels_out (n float4)
- * and argb_out (n uint32) may each be NULL.  Host buffers of 1 MiB or more that a
- * caller passes AGAIN (same address and size: a JNI caller's direct buffers) are
- * page-locked with hipHostRegister on that second use, so that later frames move
- * them by DMA; they stay registered until rm_destroy -- free them after it. */
+ * and argb_out (n uint32) may each be NULL.  (Buffers registered with
+ * rm_pin_host_buffer move by DMA at PCIe speed; others go through the runtime's
+ * pageable staging path: 6.1 vs 5.x ms per frame at BASELINE config 2.) */
 int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, int iter, int n,
                     float* pixels_out, uint32_t* argb_out);
 

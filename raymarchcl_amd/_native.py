@@ -39,7 +39,8 @@ TABLE_FLOATS = 0x4000 * 4
 # every symbol include/raymarch_hip.h declares
 EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_create_multi", "rm_num_devices",
-    "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_set_contract", "rm_synchronize", "rm_set_volume", "rm_set_volume_device",
+    "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_set_contract", "rm_synchronize", "rm_pin_host_buffer",
+    "rm_unpin_host_buffer", "rm_set_volume", "rm_set_volume_device",
     "rm_invalidate_volume", "rm_share_volume", "rm_frame_device_full", "rm_last_table_build_ms",
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
@@ -133,6 +134,8 @@ def lib():
     L.rm_synchronize.argtypes = [_vp]
     L.rm_set_seed_cast.argtypes = [_vp, _i]
     L.rm_set_contract.argtypes = [_vp, _i]
+    L.rm_pin_host_buffer.argtypes = [_vp, _vp, ctypes.c_size_t]
+    L.rm_unpin_host_buffer.argtypes = [_vp, _vp]
     L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
@@ -275,6 +278,20 @@ class Context:
 
     def synchronize(self):
         check(lib().rm_synchronize(self._h))
+
+    def pin_host_buffer(self, array):
+        """Page-lock a long-lived numpy array that render_frame_into() will be given repeatedly."""
+        check(lib().rm_pin_host_buffer(self._h, array.ctypes.data, array.nbytes))
+
+    def unpin_host_buffer(self, array):
+        check(lib().rm_unpin_host_buffer(self._h, array.ctypes.data))
+
+    def render_frame_into(self, opts_array, mc_array, n, pixels, argb):
+        """render_frame() into caller-owned arrays (e.g. pinned ones): no allocation per frame."""
+        iters = len(bytes(opts_array)) // OPTS_BYTES
+        check(lib().rm_render_frame(self._h, self._opts(opts_array, iters), _np(mc_array, np.float32, "mc_array"), iters,
+                                    n, _np(pixels, np.float32, "pixels") if pixels is not None else None,
+                                    _np(argb, np.uint32, "argb") if argb is not None else None))
 
     def set_contract(self, contract):
         """"cpu" (default): the results of an OpenCL CPU device on x86-64 (checked against the CPU

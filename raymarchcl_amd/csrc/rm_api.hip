@@ -117,12 +117,8 @@ struct rm_ctx {
   int repl_iter = 0;
   bool timed = false;
   int launches = 0;
-  // Host buffers of rm_render_frame seen more than once (a JNI caller's direct buffers, reused
-  // frame after frame) are page-locked on their second use and stay so until rm_destroy: the
-  // 4 MiB of tables up and the 18 MB of pixels back then move by DMA at PCIe speed instead of
-  // through the runtime's pageable staging path (6.2 -> 5.x ms per frame at config 2).
-  struct HostBuf { const void* p; size_t bytes; int seen; bool pinned; };
-  std::vector<HostBuf> host_bufs;
+  // rm_pin_host_buffer: caller buffers page-locked for the host-buffer entry points
+  std::vector<const void*> host_bufs;
   // rm_create_multi: the other devices of a multi-device context (this one is rank 0)
   std::vector<rm_ctx*> peers;
   rm_ctx* parent = nullptr;
@@ -473,8 +469,7 @@ void rm_destroy(rm_ctx* c) {
   c->peers.clear();
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  for (auto& h : c->host_bufs)
-    if (h.pinned) (void)hipHostUnregister(const_cast<void*>(h.p));
+  for (const void* h : c->host_bufs) (void)hipHostUnregister(const_cast<void*>(h));
   c->host_bufs.clear();
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
                     &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf};
@@ -513,6 +508,29 @@ int rm_set_contract(rm_ctx* c, int contract) {
   c->contract = contract;
   for (rm_ctx* p : c->peers) p->contract = contract;
   return RM_OK;
+}
+
+int rm_pin_host_buffer(rm_ctx* c, const void* p, size_t bytes) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!p || !bytes) return fail(RM_EINVAL, "rm_pin_host_buffer: NULL or empty buffer");
+  for (const void* h : c->host_bufs)
+    if (h == p) return RM_OK;
+  HIP_TRY(hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault));
+  c->host_bufs.push_back(p);
+  return RM_OK;
+}
+int rm_unpin_host_buffer(rm_ctx* c, const void* p) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  for (size_t i = 0; i < c->host_bufs.size(); i++)
+    if (c->host_bufs[i] == p) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      (void)hipHostUnregister(const_cast<void*>(p));
+      c->host_bufs.erase(c->host_bufs.begin() + (long)i);
+      return RM_OK;
+    }
+  return fail(RM_EINVAL, "rm_unpin_host_buffer: not a buffer rm_pin_host_buffer registered");
 }
 
 int rm_synchronize(rm_ctx* c) {
@@ -759,24 +777,6 @@ int rm_tonemap_image(rm_ctx* c, const float* pixels, const void* opts544, uint32
   return RM_OK;
 }
 
-// remember a caller's host buffer; page-lock it when it comes back (see rm_ctx::host_bufs)
-static void note_host_buffer(rm_ctx* c, const void* p, size_t bytes) {
-  if (!p || bytes < (1u << 20)) return;  // small copies gain nothing
-  for (auto& h : c->host_bufs)
-    if (h.p == p && h.bytes == bytes) {
-      if (!h.pinned && ++h.seen >= 2) {
-        if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) h.pinned = true;
-        else { (void)hipGetLastError(); h.seen = -1000000; }  // (overlaps another registration, ...): stay pageable
-      }
-      return;
-    }
-  if (c->host_bufs.size() >= 8) {  // forget the oldest
-    if (c->host_bufs.front().pinned) (void)hipHostUnregister(const_cast<void*>(c->host_bufs.front().p));
-    c->host_bufs.erase(c->host_bufs.begin());
-  }
-  c->host_bufs.push_back({p, bytes, 1, false});
-}
-
 // upload the frame's records and tables to one device (asynchronous on its stream)
 static int upload_frame_inputs(rm_ctx* c, const void* opts_array, const float* mc_array, int iter) {
   HIP_TRY(c->opts_buf.reserve((size_t)iter * RM_OPTS_BYTES));
@@ -861,9 +861,6 @@ static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc
 
 static int render_frame_host(rm_ctx* c, const void* opts_array, const float* mc_array, int iter, int n,
                              float* pixels_out, uint32_t* argb_out, bool sdf) {
-  note_host_buffer(c, mc_array, (size_t)iter * RM_TABLE_FLOATS * 4);
-  note_host_buffer(c, pixels_out, (size_t)n * 16);
-  note_host_buffer(c, argb_out, (size_t)n * 4);
   std::vector<RmOpts> recs(iter);
   memcpy(recs.data(), opts_array, (size_t)iter * RM_OPTS_BYTES);
   const int resx = recs[0].resolution[0];
