@@ -976,95 +976,6 @@ struct Tracer {
       if (mine) task_of[tasks + __popcll(mk & ((1ull << dl.lane) - 1ull))] = (uint8_t)((i << 6) | dl.lane);
       tasks += __popcll(mk);
     }
-#ifndef RM_DEAL_REFILL
-#define RM_DEAL_REFILL 8  // idle lanes take new marches when this many are idle (or nobody marches); 0 = fixed rounds
-#endif
-#if RM_DEAL_REFILL > 0
-    // Marches are dealt DYNAMICALLY, one turn group at a time: a lane whose march has ended takes
-    // the next (owner, light) pair from the list (an LDS counter) instead of waiting for the
-    // longest march of a round of 64 -- the marches of a wavefront differ several-fold in length
-    // and a phase has ~1.5 marches per lane, so fixed rounds left the lanes idle 70 % of the time.
-    // Per march the operations are those of march(.., distance_only) in the same order; the
-    // set-up of new marches is batched (RM_DEAL_REFILL idle lanes, or nobody left marching)
-    // because it runs for the whole wavefront whenever one lane needs it.
-    int* const counter = reinterpret_cast<int*>(&lds_in(6, 0));
-    if (dl.my_slot == 0) *counter = 0;
-    wave_sync();
-    bool busy = false, drained = false;
-    int e = 0, turns = 0;
-    v3 ro = V(0.f, 0.f, 0.f), rd = V(0.f, 1.f, 0.f);
-    float dist = 0.0f, lmax = 0.0f, spu = 0.0f, dir_len = 1.0f;
-    BoxFilter flt{};
-    for (;;) {
-      const bool want = !busy & !drained;
-      const unsigned long long wmask = __ballot(want), bmask = __ballot(busy);
-      if (wmask != 0ull && (__popcll(wmask) >= RM_DEAL_REFILL || bmask == 0ull)) {  // uniform
-        if (want) {
-          const int t = atomicAdd(counter, 1);
-          if (t < tasks) {
-            e = task_of[t];
-            const int light = e >> 6, owner = e & 63;
-            const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
-            const v3 ojit = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
-            // the expressions of lighting() (renderer.cl:356-362)
-            const v3 dlv = mads(ojit, o.lightScatter, ld3(o.lightPos[light])) - opos;
-            const float d2 = dot(dlv, dlv);
-            const float att = 1.0f / d2;
-            if (att > o.minLightAtt) {
-              rd = normalize(dlv);
-              lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
-              ro = muladd(rd, o.shadowBias, opos);
-              // march(ro, rd, h, lmax, shadowIter, flat, distance_only): its set-up
-              dist = o.startDist;
-              flt = make_filter(ro, rd);
-              dir_len = __builtin_amdgcn_sqrtf(dot(rd, rd)) * 0.9999f;
-              spu = samples_per_unit(o.maxVoxelIter, dir_len);
-              turns = o.shadowIter;
-              busy = true;
-            }
-          } else {
-            drained = true;
-          }
-        }
-      }
-      if (__ballot(busy) == 0ull) {
-        if (__ballot(!drained) == 0ull) break;  // uniform: nothing marching, nothing left to take
-        continue;
-      }
-      if (busy) {
-        // one group of turns of march(): the filtered turns up to the next real estimate, then it
-        float g = 0.0f;
-        int why = 2;
-        if (turns > 0) {
-          bool nw, go;
-          do {
-            turns--;
-            const float h = (rd.y * dist + ro.y) + o.groundY;
-            g = h < 1e5f ? h : 1e5f;
-            nw = surely_no_walk(flt, dist, g);
-            go = nw & !((__builtin_fabsf(g) <= o.eps) | (dist >= lmax));
-            dist = go ? dist + g : dist;
-          } while (go & (turns > 0));
-          why = go ? 2 : (nw ? 3 : 1);
-        }
-        bool done = why != 1;
-        if (!done) {
-          const bool inside = surely_inside(flt, dist, g);
-          const int limit = walk_limit_from(fminf(g, ((lmax - dist) + o.eps) * fmaxf(dir_len, 1.0f) * 1.001f), spu);
-          float sd, scode;
-          v3 nn;
-          bool cut = false;
-          scene_distance(muladd(rd, dist, ro), rd, o.maxVoxelIter, false, sd, scode, nn, inside, limit, &cut);
-          if (__builtin_fabsf(sd) <= o.eps || dist >= lmax) done = true;
-          else dist += sd;
-        }
-        if (done) {
-          lds_res(e >> 6, e & 63) = dist >= lmax ? 1000.0f : dist;
-          busy = false;
-        }
-      }
-    }
-#else
     wave_sync();
     for (int base = 0; base < tasks; base += dl.helpers) {
       const int t = base + dl.my_slot;
@@ -1086,7 +997,6 @@ struct Tracer {
         }
       }
     }
-#endif
     wave_sync();
   }
 

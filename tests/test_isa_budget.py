@@ -15,7 +15,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-KEY = "render_frame_kernelILb1ELi7ELb0ELb0ELb0ELi0E"
+# the bench instantiations: accelerated, 7 waves/SIMD, one pass group, table layout 2 (cubic power-of-two
+# grid), arithmetic contract gfx950 (bench default) and cpu
+KEYS = ["render_frame_kernelILb1ELi7ELb0ELb0ELi2ELi2E", "render_frame_kernelILb1ELi7ELb0ELb0ELi2ELi0E"]
+KEY = KEYS[0]
 
 
 @pytest.fixture(scope="module")
@@ -32,11 +35,12 @@ def frame_kernel_asm(tmp_path_factory):
     return open(out).read()
 
 
-def test_spills_stay_out_of_the_inner_loops(frame_kernel_asm):
+@pytest.mark.parametrize("key", KEYS)
+def test_spills_stay_out_of_the_inner_loops(frame_kernel_asm, key):
     import isa_spills
 
-    res = isa_spills.analyse(frame_kernel_asm.split("\n"), KEY)
-    assert res is not None, "default frame kernel instantiation not found"
+    res = isa_spills.analyse(frame_kernel_asm.split("\n"), key)
+    assert res is not None, "frame kernel instantiation not found"
     n_ins, hist, lanes, per_loop = res
     deep = {d: v for d, v in hist.items() if d >= 3}
     assert not deep, f"scratch traffic inside depth >= 3 loops: {deep}"
@@ -45,16 +49,18 @@ def test_spills_stay_out_of_the_inner_loops(frame_kernel_asm):
     assert 8000 < n_ins < 12000  # the kernel the profiles describe, not a different shape
 
 
-def test_launch_resources_of_the_default_kernel(frame_kernel_asm):
-    # kernel descriptor metadata of the default instantiation
+@pytest.mark.parametrize("key", KEYS)
+def test_launch_resources_of_the_default_kernel(frame_kernel_asm, key):
+    # kernel descriptor metadata of the bench instantiations
     m = None
     for blk in re.finditer(r"- \.agpr_count:.*?\.wavefront_size: +\d+", frame_kernel_asm, re.S):
-        if KEY in blk.group(0):
+        if key in blk.group(0):
             m = blk.group(0)
     assert m, "metadata block not found"
     get = lambda k: int(re.search(r"\." + k + r": +(\d+)", m).group(1))
     assert get("vgpr_count") <= 72          # 7 wavefronts per SIMD
     assert get("agpr_count") == 0
     assert get("group_segment_fixed_size") <= 5851  # 160 KB / 28 wavefronts per CU
-    assert get("private_segment_fixed_size") <= 256
+    assert get("private_segment_fixed_size") <= 200
+    assert get("sgpr_spill_count") == 0     # no v_writelane / v_readlane spill carriers (round 2: 61)
     assert get("wavefront_size") == 64
