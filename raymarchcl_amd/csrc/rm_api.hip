@@ -170,6 +170,7 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   // walk_step indexes with 24-bit multiplies: fall back to the plain march otherwise
   if ((long long)v.ry * v.rz >= (1 << 24) || v.rx >= (1 << 24)) return RM_OK;
   const size_t vox = (size_t)v.rx * v.ry * v.rz;
+  if (vox >= ((size_t)1 << 31)) return RM_OK;  // the kernels hold a cell index in an int
   std::lock_guard<std::mutex> lock(v.mu);
   if (v.accel_iso != iso) {
     // directional tables behind dist8 (measured -10 % frame time at 256^3, -12 % at 512^3 with
@@ -265,7 +266,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
                                   static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt, c->seed_cast,
-                                  c->contract == RM_CONTRACT_GFX950 && !counters));
+                                  c->contract == RM_CONTRACT_GFX950));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
   rm_counters got{};
   if (counters)

@@ -152,7 +152,11 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
   unsigned cell;
   if (LAYOUT == 2) {
     // (M::cell: the bare conversion instruction; scene_distance has applied M::walk_guard)
-    const int qx = M::cell(p.x * tab.fres), qy = M::cell(p.y * tab.fres), qz = M::cell(p.z * tab.fres);
+    // p and delta are in CELL units in this layout: the reference's p * res (renderer.cl:165) with res a
+    // power of two is an exact scaling that commutes with the rounding of every add (an add whose result
+    // is subnormal is exact either way), so scene_distance scales the first sample and the step once and
+    // the walk's p is, bit for bit, 2^k times the reference's at every sample
+    const int qx = M::cell(p.x), qy = M::cell(p.y), qz = M::cell(p.z);
     const bool ok = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < tab.res) & (steps > 0);  // renderer.cl:219, :221
     cell = ((((unsigned)qz << tab.sh) | (unsigned)qy) << tab.sh) | (unsigned)qx;
     d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell + (unsigned)table_off, 0, 0);
@@ -466,8 +470,13 @@ struct Tracer {
         M::walk_guard(p, delta, steps);  // (device contract: a NaN operand ends the walk where the library conversion would)
         // cells per sample along the fastest axis, padded: bounds how many samples
         // certainly stay inside the empty neighbourhood dist8 reports
-        const float s = fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
-                              __builtin_fabsf(delta.z) * frz);
+        if (LAYOUT == 2) {  // cell units (walk_step): exact, the grid edge is a power of two
+          p = p * tab_.fres;
+          delta = delta * tab_.fres;
+        }
+        const float s = LAYOUT == 2 ? fmaxf(fmaxf(__builtin_fabsf(delta.x), __builtin_fabsf(delta.y)), __builtin_fabsf(delta.z))
+                                    : fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
+                                            __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
         const float c0 = 1.0f - inv_s;
         // directional table of this walk (a walk never moves against the signs of delta)
@@ -488,6 +497,7 @@ struct Tracer {
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
           nrm = surf_normal<M>(w, smooth);
+          if (LAYOUT == 2) p = p * (1.0f / tab_.fres);  // (exact: back to the reference's units)
           const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
           const float d = length(rpos - hit) - o.voxelSize;
           if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }

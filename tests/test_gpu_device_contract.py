@@ -124,3 +124,49 @@ def test_randomised_frames_against_the_reference_build(refs):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--contract", "gfx950",
                         "--cases", "60", "--seed", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_work_item_undefined_under_the_device_arithmetic_only(native, refs, oracle_mod):
+    """Round-3 fuzz case 1369 of seed 3303, rebuilt from its parameters: ONE work-item of pass 7 differs from
+    the reference build.  Its third bounce lands, under THIS chip's arithmetic only, on a material index
+    outside the record: the reference kernel then reads its private copy of the record out of bounds
+    (renderer.cl:394,418 -- undefined), the product defines such a material as zero.  The CPU restatement
+    cannot flag it (under its arithmetic the bounce lands elsewhere); the plain algorithm run in the device
+    contract counts the lookup.  Everything else of the frame is bit-identical."""
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen, structs
+
+    base = dict(width=51, height=31, vres=[64, 64, 64], iter=8,
+                eyepos=[1.5138196778079402, 0.9110687635350511, 1.4679164504197397],
+                targetpos=[-0.20502942760479748, -0.44330606932885597, -0.20290005279972878], mat="metal",
+                fov=101.85582954649558, dof=0.001)
+    over = dict(fogPow=0.0842790072010613, aoAmp=0.37821923398069385, aoStepDist=0.27685733566557547)
+    it, n = 8, 1580
+    recs = []
+    for i in range(it):
+        o = rm.render_options(t=i * 0.333, **base)
+        o.update(over)
+        recs.append(structs.encode_bytes(o))
+    opts = b"".join(recs)
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=612096387 + i) for i in range(it)])
+    vox = scenes.volume("terrain", 64)
+    want, _, _ = refs.gfx950_render_frame(vox, opts, mc, n, build="strict", tonemap=False)
+    mask = np.zeros(n, np.uint8)
+    acc = np.zeros(4 * n, np.float32)
+    for i in range(it):
+        oracle_mod.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], acc, n=n, undefined_mask=mask)
+    assert not mask.any()  # defined everywhere under the CPU device's arithmetic
+    with native.Context(0) as ctx:
+        ctx.set_contract("gfx950")
+        ctx.set_volume(vox, [64, 64, 64])
+        px, _ = ctx.render_frame(opts, mc, n, want_argb=False)
+        items = np.nonzero((px.view(np.uint32) != want.view(np.uint32)).reshape(-1, 4).any(axis=1))[0]
+        assert list(items) == [597]
+        oob = []
+        scratch = np.zeros(4 * n, np.float32)
+        for k in range(it):  # lookups outside the record by work-item 597 alone: count(0..597) - count(0..596)
+            c1, c0 = native.Counters(), native.Counters()
+            ctx.render_image(mc[k], opts[k * 544:(k + 1) * 544], scratch, 598, counters=c1)
+            ctx.render_image(mc[k], opts[k * 544:(k + 1) * 544], scratch, 597, counters=c0)
+            oob.append(c1.oob_material - c0.oob_material)
+        assert oob[7] > 0 and sum(oob[:7]) == 0, oob
