@@ -545,7 +545,7 @@ struct Tracer {
     float before;  // t + 8e-6|t| + g < before  =>  near0 - t > g + m(t): entry farther than the ground term
                    //   (a line that misses the box by a margin gets before = 64: true while t <= 64)
     float in_lo, in_hi;  // in_lo <= t < in_hi  =>  near0 - t < -m(t) and far0 - t > m(t): inside the box
-    float slack;
+    float g_min;  // ... and the ground term must exceed this: slack + the t-proportional part for every t < in_hi
   };
   RM_DEV BoxFilter make_filter(v3 ro, v3 rd) {
     const RmOpts& o = *sc.o;
@@ -564,7 +564,6 @@ struct Tracer {
     const float far0 = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz));
     // positions are rounded to ~4e-6 and divided by >= 1e-3, quotients (< 7e4) to ~8e-3
     const float slack = 0.03f + 8e-6f * (__builtin_fabsf(near0) + __builtin_fabsf(far0));
-    f.slack = slack;
     // t(1 - 8e-6) > far0 + slack, with t >= 0
     f.past = fmaxf(far0 + slack, 0.0f) * 1.00002f;
     // the line misses the box (b < a) by more than m(64): no walk anywhere up to t = 64
@@ -572,6 +571,7 @@ struct Tracer {
     f.before = miss ? 64.0f : near0 - slack * 1.01f;
     f.in_lo = fmaxf(near0 + slack, 0.0f) * 1.00002f;
     f.in_hi = (far0 - slack) * 0.99998f;  // (<= 0: never inside)
+    f.g_min = slack + 8.1e-6f * fmaxf(f.in_hi, 0.0f);
     if (!ok) {
       f.past = __builtin_inff();
       f.before = -__builtin_inff();
@@ -590,7 +590,7 @@ struct Tracer {
   // true when the position at distance t is certainly inside the clip box and the ground
   // term is positive by a margin: the reference's slab test returns exactly +0 < g
   RM_DEV bool surely_inside(const BoxFilter& f, float t, float g) {
-    return (t >= f.in_lo) & (t < f.in_hi) & (g > __builtin_fmaf(__builtin_fabsf(t), 8e-6f, f.slack));
+    return (t >= f.in_lo) & (t < f.in_hi) & (g > f.g_min);
   }
   // distance_only: the caller uses r.distance alone (shadow rays): walks may stop where a hit
   // could no longer change it (walk_limit_for)
