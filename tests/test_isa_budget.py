@@ -64,3 +64,26 @@ def test_launch_resources_of_the_default_kernel(frame_kernel_asm, key):
     assert get("private_segment_fixed_size") <= 200
     assert get("sgpr_spill_count") == 0     # no v_writelane / v_readlane spill carriers (round 2: 61)
     assert get("wavefront_size") == 64
+
+
+def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
+    """The code-generation fault DESIGN.md 4c pins down (round 3, with rocgdb): the register allocator puts
+    the reload of a spilled VGPR into the exit block of a loop it lowered as divergent -- a block entered
+    through `s_cbranch_execz`, with NO lane enabled, in front of the `s_or_b64 exec` that brings the lanes
+    back.  The reload reaches nobody; the lanes go on with whatever the loop used the register for (seen:
+    the per-lane LDS slot address -> owners post into nowhere -> helpers fetch through a pointer made of
+    leftovers -> memory aperture violation; earlier in the round the same shape as wrong pixels).  No
+    kernel of the library may contain that shape (tools/isa_exec_lint.py; every kernel, not only the
+    bench instantiations)."""
+    import isa_exec_lint
+
+    lines = frame_kernel_asm.split("\n")
+    fatal, listed, kernels = [], 0, 0
+    for name, lo, hi in isa_exec_lint.kernels(lines):
+        kernels += 1
+        for off, reload, restore, dead in isa_exec_lint.lint(lines, lo, hi):
+            listed += 1
+            if dead:
+                fatal.append((name, off, reload))
+    assert kernels >= 40            # all instantiations of rm_kernels.hip were looked at
+    assert not fatal, fatal
