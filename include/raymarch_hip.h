@@ -214,7 +214,7 @@ int rm_render_sdf_frame(rm_ctx* ctx, const void* opts544_array, const float* mc_
 int rm_tiles_per_part(int resx, int n, int parts);
 int rm_frame_device(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
                     int width, int tile_first, int tile_stride, float* d_tiles);
-/* The unpartitioned frame in ONE kernel launch: all passes, blended in order, the row-major
+/* The unpartitioned frame in ONE kernel launch per 16 passes (one for a 16-pass frame): all passes, blended in order, the row-major
  * float4 image into d_pixels (nullable) and TonemapImage(d_opts[0]) into d_argb (nullable;
  * at least one of the two).  Same validation contract as rm_frame_device. */
 int rm_frame_device_full(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -291,17 +292,24 @@ struct FrameOut {
 
 // The pipeline of core.clj:76-97 on resident inputs: accumulator from zero, `iter` passes in
 // order.  Consecutive passes whose records are identical apart from .time (what
-// core.clj:99-106 produces) and share a hit threshold go out as ONE launch of the frame
-// kernel, pass-packed; a record that differs otherwise starts a new launch, which continues
-// from the accumulator the previous one left (launches of a stream are ordered).
+// core.clj:99-106 produces) and share a hit threshold go out pass-packed, as many per launch
+// of the frame kernel as one wavefront holds (16 by default: the whole frame of BASELINE's
+// headline configuration is ONE launch); more passes, or a record that differs otherwise,
+// start a new launch, which continues from the accumulator the previous one left (launches
+// of a stream are ordered).
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
                     const FrameOut& out, const unsigned char* same_as_prev, const RmOpts* host_recs,
                     bool sdf_frame) {
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  int launches = 0;
+  int launches = 0, run_end = 0, pp_log2 = 0;
   for (int i0 = 0; i0 < iter;) {
     int i1 = i0 + 1;
-    while (i1 < iter && same_as_prev[i1]) i1++;
+    if (run_end <= i0) {  // a new run of records that differ in .time only: its pass packing
+      run_end = i1;
+      while (run_end < iter && same_as_prev[run_end]) run_end++;
+      pp_log2 = rmk::choose_pass_pack(run_end - i0, c->pass_pack, c->pack_waste);
+    }
+    i1 = std::min(run_end, i0 + (1 << pp_log2));  // one launch = what one wavefront holds
     rmk::FrameLaunch f;
     if (sdf_frame) {  // quality mode: no derived structures
       f.sdf = static_cast<const float*>(c->sdf_buf.p);
@@ -317,7 +325,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.argb = i1 == iter ? out.argb : nullptr;
     f.resx = resx; f.n = n; f.passes = i1 - i0;
     f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
-    f.pp_log2 = rmk::choose_pass_pack(i1 - i0, c->pass_pack, c->pack_waste);
+    f.pp_log2 = pp_log2;
     f.xcd_rows = c->xcd_rows;
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;

@@ -29,9 +29,9 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
                               int id1, int tile_first, int tile_stride, bool tile_major,
                               Counters* d_counters, int seed_cast_gpu = 0, bool device_arith = false);
 // One launch of the frame kernel (rm_kernels.hip render_frame_kernel): `passes` consecutive
-// RenderImage passes over partition (tile_first, tile_stride) of the image, blended in order
-// into `acc`.  pp_log2 > 0: a wavefront holds 2^pp_log2 passes of 64/2^pp_log2 pixels -- only
-// valid when the records are identical except .time.
+// RenderImage passes (at most 2^pp_log2: what one wavefront holds) over partition (tile_first, tile_stride)
+// of the image, blended in order into `acc`.  pp_log2 > 0: a wavefront holds 2^pp_log2 passes of
+// 64/2^pp_log2 pixels -- only valid when the records are identical except .time.
 struct FrameLaunch {
   const uint8_t* vox = nullptr;
   Accel accel;

@@ -141,11 +141,12 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
   return 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
 }
 
-// MULTI = the launch holds more passes than a wavefront does (the loop over groups of passes
-// exists only then: a single group keeps nothing alive across the body of a sample)
+// A launch holds at most the passes ONE wavefront holds (2^pp_log2): frames with more passes go out as several
+// launches that continue each other's accumulator (rm_api.hip frame_on_device) -- nothing of a sample then lives
+// across the body of another, and the kernel has no loop over groups of passes.
 // ARITH: 0 = OpenCL CPU device arithmetic and casts, 1 = the same with the GPU lowering of the seed
 // casts, 2 = ROCm's OpenCL library on this GPU (rm_math.hpp)
-template <bool ACCEL, bool SDFM, bool MULTI, int LAYOUT, int ARITH>
+template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
   using M = typename std::conditional<ARITH == 2, rmk::MathOcl, rmk::MathX86<(ARITH == 1 ? 1 : 0)>>::type;
   using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     const float4 p = a.acc[at];
     px = p.x; py = p.y; pz = p.z;
   }
-  for (int c0 = 0; MULTI ? c0 < a.passes : c0 == 0; c0 += MULTI ? pp : 1) {
+  for (int c0 = 0; c0 == 0; c0 += 1) {  // (one group: c0 = first pass of the group this wavefront holds = of the launch)
     const int pass = c0 + pl;
     const bool live = pass < a.passes;
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
@@ -226,11 +227,11 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   }
 }
 
-template <bool ACCEL, int MINW, bool SDFM, bool MULTI, int LAYOUT = 0, int ARITH = 0>
+template <bool ACCEL, int MINW, bool SDFM, int LAYOUT = 0, int ARITH = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
   __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
-  frame_block<ACCEL, SDFM, MULTI, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
+  frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
 }
 
 template <bool DEVICE>
@@ -373,9 +374,10 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   return hipGetLastError();
 }
 
-// log2 of the passes per wavefront for a run of `passes` records that differ in .time only:
-// the largest k <= max_log2 whose last group leaves at most waste_pct % of the lane turns
-// without a pass (k = 0 never leaves any)
+// log2 of the passes per wavefront (= per launch) for a run of `passes` records that differ in .time only:
+// the largest k <= max_log2 whose last group leaves at most waste_pct % of the run's lane turns
+// without a pass (k = 0 never leaves any).  Lanes without a pass still trace the other lanes'
+// secondary rays: 25 passes as 16 + 9 measured 12 % faster than as 6 x 4 + 1.
 int choose_pass_pack(int passes, int max_log2, int waste_pct) {
   for (int k = max_log2; k >= 1; k--) {
     const int pp = 1 << k;
@@ -418,16 +420,12 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.accumulate = f.accumulate ? 1 : 0;
   a.row_major = f.row_major ? 1 : 0;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  const bool multi = f.passes > (1 << pp_log2);
+  if (f.passes > (1 << pp_log2)) return hipErrorInvalidValue;  // (the caller splits a run into such launches)
 // (7 wavefronts per SIMD = 72 VGPRs measured best: 6 +3.5 %, 8 +2.5 %, 5 +14 %; -DRM_FRAME_MINW=n re-measures)
 #ifndef RM_FRAME_MINW
 #define RM_FRAME_MINW 7
 #endif
-#define RM_FRAME(A, W, S, B, G)                                                     \
-  do {                                                                              \
-    if (multi) render_frame_kernel<A, W, S, true, B, G><<<grid, block, 0, st>>>(a);  \
-    else render_frame_kernel<A, W, S, false, B, G><<<grid, block, 0, st>>>(a);       \
-  } while (0)
+#define RM_FRAME(A, W, S, B, G) render_frame_kernel<A, W, S, B, G><<<grid, block, 0, st>>>(a)
 #define RM_FRAME_ARITH(A, W, S, B)                  \
   do {                                              \
     if (f.arith == 2) RM_FRAME(A, W, S, B, 2);      \

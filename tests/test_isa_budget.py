@@ -15,9 +15,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-# the bench instantiations: accelerated, 7 waves/SIMD, one pass group, table layout 2 (cubic power-of-two
+# the bench instantiations: accelerated, 7 waves/SIMD, table layout 2 (cubic power-of-two
 # grid), arithmetic contract gfx950 (bench default) and cpu
-KEYS = ["render_frame_kernelILb1ELi7ELb0ELb0ELi2ELi2E", "render_frame_kernelILb1ELi7ELb0ELb0ELi2ELi0E"]
+KEYS = ["render_frame_kernelILb1ELi7ELb0ELi2ELi2E", "render_frame_kernelILb1ELi7ELb0ELi2ELi0E"]
 KEY = KEYS[0]
 
 
@@ -85,5 +85,5 @@ def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
             listed += 1
             if dead:
                 fatal.append((name, off, reload))
-    assert kernels >= 40            # all instantiations of rm_kernels.hip were looked at
+    assert kernels >= 30            # all instantiations of rm_kernels.hip were looked at
     assert not fatal, fatal

@@ -9,5 +9,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY \
   -d $OUT/p1 -o pmc -- python $R/bench.py --no-cpu-baseline --steps 6 --warmup 2 --frames-in-flight 1 "$@" > $OUT/p1.log 2>&1
 cd $R
-python tools/pmc_summary.py $OUT/p1/pmc_results.db --kernel "render_frame_kernel<true, 7, false, false, 2, 2>" | grep avg
+python tools/pmc_summary.py $OUT/p1/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 2, 2>" | grep avg
 rm -rf $OUT/p1
