@@ -87,3 +87,13 @@ def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
                 fatal.append((name, off, reload))
     assert kernels >= 30            # all instantiations of rm_kernels.hip were looked at
     assert not fatal, fatal
+
+
+def test_no_kernel_of_the_library_spills_an_sgpr(frame_kernel_asm):
+    """Round 2's hazard (spill lanes of a VGPR also handed to a vector value) needs spilled SGPRs: since the
+    in-kernel loop over pass groups is gone, no kernel of the library has any."""
+    n = 0
+    for blk in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", frame_kernel_asm, re.S):
+        n += 1
+        assert int(re.search(r"sgpr_spill_count:\s+(\d+)", blk.group(2)).group(1)) == 0, blk.group(1)
+    assert n >= 30
