@@ -10,6 +10,10 @@
 # tools/diag_cast.py then switches phases off through the option record: the wrong pixels need a
 # light that passes the attenuation test (numLights > 0, minLightAtt small) and nothing else.
 #
+# (Written against the sources of commit 11be60c, built without the two -mllvm switches; kept for the record.  With
+#  today's sources and flags the allocation is another one -- the live reproducer, with the faulting instruction
+#  identified, is tools/repro_reload_exec0.sh.)
+#
 #   build container:  tools/repro_gpucast_fault.sh build
 #   GPU box:          tools/repro_gpucast_fault.sh run     (gpurun -- tools/repro_gpucast_fault.sh run)
 R=${GRAFT_REPO_ROOT:-/root/repo}
