@@ -97,6 +97,37 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def lint_kernels():
+    """Compile the kernels to gfx950 assembly with the product flags and look for the two shapes
+    of the compiler fault DESIGN.md 4c describes: a spill reload in a block that is entered with
+    exec = 0 (tools/isa_exec_lint.py), and spilled SGPRs.  Raises RmError if either is present --
+    a library built from such code renders wrong or faults in some instantiations, silently.
+    (__graft_entry__.build() and tests/test_isa_budget.py run this; ~35 s, no GPU.)"""
+    import re
+    import sys
+    import tempfile
+
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import isa_exec_lint
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(CSRC, "rm_kernels.hip"), "-o", out],
+                       check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    lines = text.split("\n")
+    fatal = [(name, off, reload) for name, lo, hi in isa_exec_lint.kernels(lines)
+             for off, reload, _restore, dead in isa_exec_lint.lint(lines, lo, hi) if dead]
+    sgpr = [m.group(1) for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*?)\.sgpr_spill_count:\s+(\d+)", text, re.S)
+            if int(m.group(2)) > 0]
+    if fatal or sgpr:
+        raise RmError(-3, f"kernel build hits the compiler fault of DESIGN.md 4c: reloads under exec = 0: {fatal[:4]}; "
+                          f"kernels with spilled SGPRs: {sgpr[:4]}")
+    return len(list(isa_exec_lint.kernels(lines)))
+
+
 _lib = None
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
