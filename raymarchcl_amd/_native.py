@@ -112,11 +112,15 @@ def lint_kernels():
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = [f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    text = ""
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(CSRC, "rm_kernels.hip"), "-o", out],
-                       check=True, stderr=subprocess.DEVNULL)
-        text = open(out).read()
+        for src in SOURCES:
+            if not src.endswith(".hip"):
+                continue
+            out = os.path.join(d, src + ".s")
+            subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out],
+                           check=True, stderr=subprocess.DEVNULL)
+            text += open(out).read() + "\n"
     lines = text.split("\n")
     fatal = [(name, off, reload) for name, lo, hi in isa_exec_lint.kernels(lines)
              for off, reload, _restore, dead in isa_exec_lint.lint(lines, lo, hi) if dead]
