@@ -97,3 +97,56 @@ def test_no_kernel_of_the_library_spills_an_sgpr(frame_kernel_asm):
         n += 1
         assert int(re.search(r"sgpr_spill_count:\s+(\d+)", blk.group(2)).group(1)) == 0, blk.group(1)
     assert n >= 30
+
+
+def test_the_lint_recognises_the_shape_and_nothing_else():
+    """tools/isa_exec_lint.py on hand-written assembly: the fatal shape (reload in a loop-exit block that is
+    only entered through s_cbranch_execz, in front of the exec restore), the same with the exit reached by
+    falling out of an s_cbranch_execnz loop, and two harmless neighbours (a reload after the restore; a
+    reload at the end of an `if` region under the region's own mask)."""
+    import isa_exec_lint
+
+    def kernel(body):
+        return ("_Zk:\n" + body + "\n.Lfunc_end0:\n").split("\n")
+
+    fatal = """
+.LBB0_1:
+	v_add_f32_e32 v1, v1, v2
+	s_andn2_b64 exec, exec, s[4:5]
+	s_cbranch_execz .LBB0_2
+	s_branch .LBB0_1
+.LBB0_2:
+	scratch_load_dword v1, off, off offset:4 ; 4-byte Folded Reload
+.LBB0_3:
+	s_or_b64 exec, exec, s[6:7]
+	s_endpgm"""
+    fallthrough = """
+.LBB0_1:
+	v_add_f32_e32 v1, v1, v2
+	s_andn2_b64 exec, exec, s[4:5]
+	s_cbranch_execnz .LBB0_1
+.LBB0_2:
+	scratch_load_dword v1, off, off offset:4 ; 4-byte Folded Reload
+	s_or_b64 exec, exec, s[6:7]
+	s_endpgm"""
+    after_restore = """
+.LBB0_1:
+	s_andn2_b64 exec, exec, s[4:5]
+	s_cbranch_execz .LBB0_2
+	s_branch .LBB0_1
+.LBB0_2:
+	s_or_b64 exec, exec, s[6:7]
+	scratch_load_dword v1, off, off offset:4 ; 4-byte Folded Reload
+	s_endpgm"""
+    end_of_if = """
+	s_and_saveexec_b64 s[6:7], vcc
+	s_cbranch_execz .LBB0_2
+	v_mov_b32_e32 v1, v3
+	scratch_load_dword v1, off, off offset:4 ; 4-byte Folded Reload
+.LBB0_2:
+	s_or_b64 exec, exec, s[6:7]
+	s_endpgm"""
+    for body, want in ((fatal, 1), (fallthrough, 1), (after_restore, 0), (end_of_if, 0)):
+        lines = kernel(body)
+        (name, lo, hi), = list(isa_exec_lint.kernels(lines))
+        assert sum(1 for x in isa_exec_lint.lint(lines, lo, hi) if x[3]) == want, body
