@@ -99,8 +99,8 @@ def build(force=False, verbose=False):
 
 def lint_kernels():
     """Compile the kernels to gfx950 assembly with the product flags and look for the two shapes
-    of the compiler fault DESIGN.md 4c describes: a spill reload in a block that is entered with
-    exec = 0 (tools/isa_exec_lint.py), and spilled SGPRs.  Raises RmError if either is present --
+    of the compiler fault DESIGN.md 4c describes: a spill reload or an allocator-inserted copy in a
+    block that is entered with exec = 0 (tools/isa_exec_lint.py), and spilled SGPRs.  Raises RmError if either is present --
     a library built from such code renders wrong or faults in some instantiations, silently.
     (__graft_entry__.build() and tests/test_isa_budget.py run this; ~35 s, no GPU.)"""
     import re
@@ -122,12 +122,12 @@ def lint_kernels():
                            check=True, stderr=subprocess.DEVNULL)
             text += open(out).read() + "\n"
     lines = text.split("\n")
-    fatal = [(name, off, reload) for name, lo, hi in isa_exec_lint.kernels(lines)
-             for off, reload, _restore, dead in isa_exec_lint.lint(lines, lo, hi) if dead]
+    fatal = [(name, off, ins) for name, lo, hi in isa_exec_lint.kernels(lines)
+             for off, ins in isa_exec_lint.dead_vector_instructions(lines, lo, hi)]
     sgpr = [m.group(1) for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*?)\.sgpr_spill_count:\s+(\d+)", text, re.S)
             if int(m.group(2)) > 0]
     if fatal or sgpr:
-        raise RmError(-3, f"kernel build hits the compiler fault of DESIGN.md 4c: reloads under exec = 0: {fatal[:4]}; "
+        raise RmError(-3, f"kernel build hits the compiler fault of DESIGN.md 4c: vector instructions under exec = 0: {fatal[:4]}; "
                           f"kernels with spilled SGPRs: {sgpr[:4]}")
     return len(list(isa_exec_lint.kernels(lines)))
 

@@ -78,13 +78,14 @@ def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
     import isa_exec_lint
 
     lines = frame_kernel_asm.split("\n")
-    fatal, listed, kernels = [], 0, 0
+    fatal, kernels = [], 0
     for name, lo, hi in isa_exec_lint.kernels(lines):
         kernels += 1
         for off, reload, restore, dead in isa_exec_lint.lint(lines, lo, hi):
-            listed += 1
             if dead:
                 fatal.append((name, off, reload))
+        # the same for ANY vector instruction (the allocator's live-range copies land there too)
+        fatal += [(name, off, ins) for off, ins in isa_exec_lint.dead_vector_instructions(lines, lo, hi)]
     assert kernels >= 30            # all instantiations of rm_kernels.hip were looked at
     assert not fatal, fatal
 
@@ -146,7 +147,12 @@ def test_the_lint_recognises_the_shape_and_nothing_else():
 .LBB0_2:
 	s_or_b64 exec, exec, s[6:7]
 	s_endpgm"""
+    copy = fatal.replace("scratch_load_dword v1, off, off offset:4 ; 4-byte Folded Reload", "v_mov_b32_e32 v1, v9")
     for body, want in ((fatal, 1), (fallthrough, 1), (after_restore, 0), (end_of_if, 0)):
         lines = kernel(body)
         (name, lo, hi), = list(isa_exec_lint.kernels(lines))
         assert sum(1 for x in isa_exec_lint.lint(lines, lo, hi) if x[3]) == want, body
+        assert len(isa_exec_lint.dead_vector_instructions(lines, lo, hi)) == want, body
+    lines = kernel(copy)  # an allocator copy instead of a reload: not a reload, but just as dead
+    (name, lo, hi), = list(isa_exec_lint.kernels(lines))
+    assert not isa_exec_lint.lint(lines, lo, hi) and len(isa_exec_lint.dead_vector_instructions(lines, lo, hi)) == 1

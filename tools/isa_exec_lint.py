@@ -35,27 +35,50 @@ def kernels(lines):
 NEUTRAL = re.compile(r"^\s*(s_waitcnt|s_nop|; wave barrier|s_barrier|;)")
 
 
+LABEL = re.compile(r"^(\.LBB\d+_\d+):")
+EXEC_WRITE = re.compile(r"^\s*s_\w+ exec,|^\s*s_\w+saveexec")
+_cache = {}
+
+
+def zero_entry_blocks(lines, lo, hi):
+    """Line numbers of the labels of all blocks that can only be entered with exec = 0: every branch to
+    the label is an `s_cbranch_execz`, and the block above does not fall in with lanes enabled (it ends in
+    an unconditional branch, or in the `s_cbranch_execnz` back edge of a loop -- falling out of that also
+    means no lane is left)."""
+    key = (id(lines), lo, hi)
+    if key in _cache:
+        return _cache[key]
+    refs = {}
+    for l in lines[lo:hi]:
+        m = re.match(r"^\s*(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", l)
+        if m:
+            refs.setdefault(m.group(2), []).append(m.group(1))
+    out = set()
+    for b in range(lo, hi):
+        m = LABEL.match(lines[b])
+        if not m:
+            continue
+        k = b - 1
+        while k > lo and (not lines[k].strip() or lines[k].lstrip().startswith(";")):
+            k -= 1
+        falls_in = not re.match(r"^\s*(s_branch|s_endpgm|s_setpc|s_cbranch_execnz)", lines[k])
+        zero_fall = bool(re.match(r"^\s*s_cbranch_execnz", lines[k]))
+        r = refs.get(m.group(1), [])
+        if (not falls_in) and (r or zero_fall) and all(x == "s_cbranch_execz" for x in r):
+            out.add(b)
+    _cache[key] = out
+    return out
+
+
 def arrives_with_exec_zero(lines, lo, hi, i):
-    """True when the block holding line i can only be entered through `s_cbranch_execz` (every lane has
-    left: the exit of a divergent loop, an empty `if`) and nothing in the block before line i writes exec."""
+    """True when the block holding line i can only be entered with exec = 0 and nothing in the block
+    before line i writes exec."""
     b = i
-    while b > lo and not re.match(r"^\.LBB\d+_\d+:", lines[b]):
-        if re.match(r"^\s*s_\w+ exec,|^\s*s_\w+saveexec", lines[b]):
-            return False  # exec rewritten inside the block before the reload
+    while b > lo and not LABEL.match(lines[b]):
+        if EXEC_WRITE.match(lines[b]):
+            return False  # exec rewritten inside the block before line i
         b -= 1
-    m = re.match(r"^(\.LBB\d+_\d+):", lines[b])
-    if not m:
-        return False
-    label = m.group(1)
-    # fall-through from the block above?
-    k = b - 1
-    while k > lo and (not lines[k].strip() or lines[k].lstrip().startswith(";")):
-        k -= 1
-    # (falling out of a loop whose back edge is `s_cbranch_execnz` also means: no lane left)
-    falls_in = not re.match(r"^\s*(s_branch|s_endpgm|s_setpc|s_cbranch_execnz)", lines[k])
-    zero_fall = bool(re.match(r"^\s*s_cbranch_execnz", lines[k]))
-    refs = [l for l in lines[lo:hi] if re.search(re.escape(label) + r"\b", l) and not l.startswith(label)]
-    return (not falls_in) and (bool(refs) or zero_fall) and all(re.match(r"^\s*s_cbranch_execz", r) for r in refs)
+    return b in zero_entry_blocks(lines, lo, hi)
 
 
 def lint(lines, lo, hi):
@@ -79,6 +102,26 @@ def lint(lines, lo, hi):
     return found
 
 
+VECTOR = re.compile(r"^\s*(v_|ds_|buffer_|global_|scratch_|flat_)")
+
+
+def dead_vector_instructions(lines, lo, hi):
+    """Every vector instruction that sits in a block entered with exec = 0 before anything rewrites exec:
+    reloads (above), but also the register COPIES the allocator inserts (`v_mov_b32 vA, vB` when it splits a
+    live range) -- under exec = 0 none of them does anything, so none of them can have been meant."""
+    found = []
+    for b in sorted(zero_entry_blocks(lines, lo, hi)):
+        j = b + 1
+        while j < hi and not LABEL.match(lines[j]) and not lines[j].startswith(".Lfunc_end"):
+            t = lines[j]
+            if EXEC_WRITE.match(t):
+                break
+            if VECTOR.match(t):
+                found.append((j - lo, t.strip()))
+            j += 1
+    return found
+
+
 def main():
     lines = open(sys.argv[1]).read().split("\n")
     key = sys.argv[2] if len(sys.argv) > 2 else ""
@@ -94,7 +137,16 @@ def main():
             for off, a, b, dead in f:
                 print(f"    +{off}: {a}   ->   {b}" + ("   ** block entered with exec = 0: the reload reaches NO lane **" if dead else ""))
     print(f"{sus} reload(s) in front of an exec restore, {bad} of them in a block that is entered with exec = 0")
-    return 1 if bad else 0
+    other = 0
+    for name, lo, hi in kernels(lines):
+        if key and key not in name:
+            continue
+        for off, ins in dead_vector_instructions(lines, lo, hi):
+            if "Folded Reload" not in ins:
+                other += 1
+                print(f"{name} +{off}: {ins}   ** vector instruction in a block entered with exec = 0 **")
+    print(f"{other} other vector instruction(s) in blocks entered with exec = 0")
+    return 1 if (bad or other) else 0
 
 
 if __name__ == "__main__":
