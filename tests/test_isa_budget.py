@@ -91,8 +91,9 @@ def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
 
 
 def test_no_kernel_of_the_library_spills_an_sgpr(frame_kernel_asm):
-    """Round 2's hazard (spill lanes of a VGPR also handed to a vector value) needs spilled SGPRs: since the
-    in-kernel loop over pass groups is gone, no kernel of the library has any."""
+    """Round 2 blamed spilled SGPRs (spill lanes of a VGPR also handed to a vector value) for the fault that
+    round 3 traced to misplaced spill code; never confirmed, but since the in-kernel loop over pass groups is
+    gone no kernel of the library spills an SGPR, and it stays that way."""
     n = 0
     for blk in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", frame_kernel_asm, re.S):
         n += 1
