@@ -21,9 +21,6 @@
 #include <cstdint>
 
 #define RM_DEV __device__ __forceinline__
-#ifndef RM_F2U_GPU_ASM
-#define RM_F2U_GPU_ASM 0
-#endif
 
 namespace rmd {
 
@@ -40,16 +37,10 @@ RM_DEV int32_t f2i(float x) {
 RM_DEV uint32_t f2u_gpu(float x) {
   // what v_cvt_u32_f32 does -- truncate, saturate to [0, 2^32 - 1], NaN -> 0 -- written so that no
   // C cast is out of range (the compiler folds the comparisons around one v_cvt_u32_f32)
-#if RM_F2U_GPU_ASM
-  // REPRODUCER ONLY (tools/repro_gpucast_fault.sh): the instruction itself through inline asm.
-  // With this form the 6- and 7-waves/SIMD instantiations of the accelerated frame kernel render
-  // ~80 % of the pixels wrong while 5 and 8 are right -- never the product.
-  uint32_t r;
-  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-#else
+  // (The instruction itself through inline asm -- asm("v_cvt_u32_f32 %0, %1") -- computes the same value; that
+  //  spelling was the round's first reproducer of the compiler fault of DESIGN.md 4c, see
+  //  tools/repro_gpucast_fault.sh and git commit 11be60c.)
   return x > 0.0f ? (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x) : 0u;
-#endif
 }
 RM_DEV uint32_t f2u(float x) {
   if (!(x >= -9223372036854775808.0f && x < 9223372036854775808.0f)) return 0u;

@@ -10,9 +10,10 @@
 # tools/diag_cast.py then switches phases off through the option record: the wrong pixels need a
 # light that passes the attenuation test (numLights > 0, minLightAtt small) and nothing else.
 #
-# (Written against the sources of commit 11be60c, built without the two -mllvm switches; kept for the record.  With
-#  today's sources and flags the allocation is another one -- the live reproducer, with the faulting instruction
-#  identified, is tools/repro_reload_exec0.sh.)
+# (Works on the sources of commit 11be60c -- `git worktree add /tmp/w 11be60c`, built without the two -mllvm switches;
+#  today's sources no longer carry the -DRM_F2U_GPU_ASM knob.  tools/isa_exec_lint.py on the assembly of that build finds
+#  the allocator copy in an exec = 0 block that explains it; the live reproducer, with the faulting instruction
+#  identified under rocgdb, is tools/repro_reload_exec0.sh.)
 #
 #   build container:  tools/repro_gpucast_fault.sh build
 #   GPU box:          tools/repro_gpucast_fault.sh run     (gpurun -- tools/repro_gpucast_fault.sh run)
