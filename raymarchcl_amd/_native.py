@@ -413,7 +413,7 @@ class Context:
                                     d_tiles))
 
     def frame_device_full(self, d_opts, d_mc, iters, n, width, d_pixels=None, d_argb=None):
-        """The unpartitioned frame in one launch: row-major pixels and / or ARGB; asynchronous."""
+        """The unpartitioned frame, one launch per 16 passes: row-major pixels and / or ARGB; asynchronous."""
         check(lib().rm_frame_device_full(self._h, d_opts, d_mc, iters, n, width, d_pixels, d_argb))
 
     def last_table_build_ms(self):

@@ -14,7 +14,7 @@ any partition of the image gives bit-identical pixels.  Layout:
   (torch.distributed -> RCCL over xGMI: point-to-point sends into the root, all
   links concurrently); the root un-permutes + tonemaps (rm_resolve_device).
 * with ONE rank there is no partition: the frame kernel writes the row-major image and the
-  ARGB words itself (rm_frame_device_full), one launch per frame.
+  ARGB words itself (rm_frame_device_full), one launch per frame of up to 16 passes.
 
 The volume, the scatter tables and the option records are replicated.
 """
