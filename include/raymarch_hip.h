@@ -101,16 +101,27 @@ int rm_set_seed_cast(rm_ctx* ctx, int mode);
 /* The arithmetic contract: WHICH OpenCL device's results the kernels reproduce.  The reference
  * source leaves the value of its 21 math built-ins (mad, mix, dot, normalize, length, min, max,
  * clamp, exp, exp2, pow, ...) and of its (int)/(uint) casts to the device it is built for.
- *   RM_CONTRACT_CPU_DEVICE (default): an OpenCL CPU device on x86-64 -- built-ins as the OpenCL
- *     1.2 specification defines them operation by operation, x86-64 cast lowering (seed casts per
- *     rm_set_seed_cast).  Checked bit for bit against the CPU oracle (oracle/).
- *   RM_CONTRACT_GFX950: this GPU -- the built-ins ARE ROCm's OpenCL built-in library (opencl.bc /
- *     ocml, linked into the kernels by the symbols the reference kernel links against), casts as
- *     gfx950 lowers them.  Checked bit for bit, on the GPU, against the unmodified renderer.cl
- *     built by ROCm's OpenCL compiler for gfx950 with -ffp-contract=off and correctly rounded
- *     divide/sqrt (oracle/_ref/renderer_gfx950_strict.hsaco, tests/test_gpu_device_contract.py).
- * Applies to every later render / tonemap / resolve call of the context (all its devices); the
- * quality mode (rm_render_sdf_frame) and the counting variant always use the first. */
+ *   RM_CONTRACT_GFX950 (default since ABI 3): this GPU -- the built-ins ARE ROCm's OpenCL built-in
+ *     library (opencl.bc / ocml, linked into the kernels by the symbols the reference kernel links
+ *     against), casts as gfx950 lowers them.  Checked bit for bit, on the GPU, against the
+ *     unmodified renderer.cl built by ROCm's OpenCL compiler for gfx950 with -ffp-contract=off
+ *     -cl-fp32-correctly-rounded-divide-sqrt (oracle/_ref/renderer_gfx950_strict.hsaco and its
+ *     recorded outputs tests/golden/gfx950_strict/, tests/test_gpu_device_contract.py).  NOT the
+ *     reference's own build options (-cl-fast-relaxed-math -cl-mad-enable, core.clj:128): builds
+ *     of the reference with different options disagree with each other on the hit/miss decisions
+ *     of some pixels, so no implementation equals all of them; against the reference's own options
+ *     this contract agrees exactly as well as two builds of the reference agree with each other
+ *     (tests/test_gpu_pin_gfx950.py).  The default because it is the contract with the stronger pin
+ *     (no stand-in anywhere in its checker) and the faster kernels.
+ *   RM_CONTRACT_CPU_DEVICE: an OpenCL CPU device on x86-64 (BASELINE config 1's device) -- built-ins
+ *     as the OpenCL 1.2 specification defines them operation by operation, x86-64 cast lowering
+ *     (seed casts per rm_set_seed_cast).  Checked bit for bit against the CPU oracle (oracle/).
+ * Applies to every later render / tonemap / resolve call of the context (all its devices),
+ * including the counting variant rm_render_image_counted (the plain reference algorithm under the
+ * context's contract).  The quality mode (rm_render_sdf_frame) always renders with the CPU-device
+ * arithmetic; note that rm_tonemap_image / rm_resolve_device applied to ITS accumulators by the
+ * caller follow the context's contract, while the ARGB words rm_render_sdf_frame itself returns
+ * are tonemapped with the CPU-device arithmetic. */
 #define RM_CONTRACT_CPU_DEVICE 0
 #define RM_CONTRACT_GFX950 1
 int rm_set_contract(rm_ctx* ctx, int contract);
@@ -216,7 +227,12 @@ int rm_frame_device(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter
                     int width, int tile_first, int tile_stride, float* d_tiles);
 /* The unpartitioned frame in ONE kernel launch per 16 passes (one for a 16-pass frame): all passes, blended in order, the row-major
  * float4 image into d_pixels (nullable) and TonemapImage(d_opts[0]) into d_argb (nullable;
- * at least one of the two).  Same validation contract as rm_frame_device. */
+ * at least one of the two).  Same validation contract as rm_frame_device.
+ * On a multi-device context (rm_create_multi) the frame is tiled over its devices; the records and
+ * tables are copied from the root's memory to the other devices when (d_opts, d_mc, iter) differ
+ * from the previous call's, after rm_check_device_opts, and after any rm_render_frame on the
+ * context -- NOT when a caller rewrites the contents behind unchanged pointers: call
+ * rm_check_device_opts again after changing records or scatter tables in place. */
 int rm_frame_device_full(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
                          int width, float* d_pixels, uint32_t* d_argb);
 /* Un-permute `parts` partitions' accumulators (d_tiles_all = partition 0's

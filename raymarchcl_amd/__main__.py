@@ -43,9 +43,11 @@ def main(argv=None):
     r.add_argument("--gamma", type=float, default=None)
     r.add_argument("--seed", type=int, default=1000, help="seed of the scatter tables")
     r.add_argument("--device", type=int, default=0)
-    r.add_argument("--contract", default="cpu", choices=["cpu", "gfx950"],
-                   help="whose results the kernels reproduce: an OpenCL CPU device (default) or the reference kernel "
-                        "as ROCm's OpenCL compiler builds it for this GPU (include/raymarch_hip.h rm_set_contract)")
+    r.add_argument("--contract", default="gfx950", choices=["cpu", "gfx950"],
+                   help="whose results the kernels reproduce: gfx950 (default) = the reference kernel built by ROCm's "
+                        "OpenCL compiler for this GPU with -ffp-contract=off and correctly rounded divide/sqrt (NOT the "
+                        "reference's own -cl-fast-relaxed-math build, which no implementation can equal bit for bit); "
+                        "cpu = an OpenCL CPU device on x86-64 (include/raymarch_hip.h rm_set_contract)")
     args = ap.parse_args(argv)
 
     from . import core, generators, vio

@@ -29,9 +29,17 @@ DEVICE_LIBS = ["opencl.bc", "ocml.bc", "ockl.bc", "oclc_daz_opt_off.bc", "oclc_u
 # kernel that render wrong pixels (shadow results of the wave-shared phases go missing) depending on
 # the register budget -- reproduced, bisected and described in DESIGN.md section 4c
 # (tools/repro_gpucast_fault.sh).  Cost of switching them off: 0-4 % of the frame time.
+# (the ROCm tree comes from ROCM_PATH / HIPCC like hipcc's own; the code-object version is spelled out so
+#  that it cannot drift away from the oclc_abi_version_600 bitcode named above)
+ROCM_PATH = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared", "-mllvm", "-disable-machine-sink", "-mllvm", "-disable-machine-licm",
-               "--hip-device-lib-path=/opt/rocm/amdgcn/bitcode"] + ["--hip-device-lib=" + b for b in DEVICE_LIBS]
+               "-shared", "-mcode-object-version=6", "-mllvm", "-disable-machine-sink", "-mllvm", "-disable-machine-licm",
+               "--hip-device-lib-path=" + os.path.join(ROCM_PATH, "amdgcn", "bitcode")] + \
+              ["--hip-device-lib=" + b for b in DEVICE_LIBS]
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", os.path.join(ROCM_PATH, "bin", "hipcc"))
 
 OPTS_BYTES = 544
 TABLE_FLOATS = 0x4000 * 4
@@ -85,32 +93,40 @@ def _stale():
     return any(os.path.getmtime(f) > t for f in files if os.path.isfile(f))
 
 
-def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree."""
+def build(force=False, verbose=False, lint=None):
+    """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree.  A real compile of the
+    PRODUCT library is followed by lint_kernels() (the generated code must be free of the compiler
+    fault of DESIGN.md 4c; ~35 s): a library that fails it is removed again and the call raises.
+    lint=False skips that (A/B variants: RAYMARCH_LIB names another file)."""
     if not force and not _stale():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if lint is None:
+        lint = os.path.basename(LIB_PATH) == "libraymarch_hip.so" and os.environ.get("RAYMARCH_SKIP_LINT", "0") != "1"
+    if lint:
+        try:
+            lint_kernels()
+        except RmError:
+            os.remove(LIB_PATH)
+            raise
     return LIB_PATH
 
 
 def lint_kernels():
     """Compile the kernels to gfx950 assembly with the product flags and look for the two shapes
     of the compiler fault DESIGN.md 4c describes: a spill reload or an allocator-inserted copy in a
-    block that is entered with exec = 0 (tools/isa_exec_lint.py), and spilled SGPRs.  Raises RmError if either is present --
+    block that is entered with exec = 0 (isa_exec_lint.py of this package), and spilled SGPRs.  Raises RmError if either is present --
     a library built from such code renders wrong or faults in some instantiations, silently.
-    (__graft_entry__.build() and tests/test_isa_budget.py run this; ~35 s, no GPU.)"""
+    (build() runs this after every real compile of the product library; tests/test_isa_budget.py too; ~35 s, no GPU.)"""
     import re
-    import sys
     import tempfile
 
-    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
-    import isa_exec_lint
+    from . import isa_exec_lint
 
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hipcc = _hipcc()
     flags = [f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
     text = ""
     with tempfile.TemporaryDirectory() as d:
@@ -208,12 +224,18 @@ def _np(a, dtype, name):
     return a.ctypes.data
 
 
+# Arithmetic contract applied to every Context created without an explicit one; None = the
+# library's own default (RM_CONTRACT_GFX950).  Test modules that check the CPU-device contract
+# against the CPU oracle set this to "cpu" for their duration.
+DEFAULT_CONTRACT = None
+
+
 class Context:
     """Owns one rm_ctx (one device, one stream)."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, contract=None):
         """device_id: a HIP ordinal, or a sequence of ordinals for one frame spread over several
-        devices (rm_create_multi; ordinals may repeat)."""
+        devices (rm_create_multi; ordinals may repeat).  contract: "gfx950" (library default) / "cpu"."""
         self._h = _vp()
         if isinstance(device_id, (list, tuple)):
             ids = (_i * len(device_id))(*[int(d) for d in device_id])
@@ -222,6 +244,9 @@ class Context:
             check(lib().rm_create(int(device_id), ctypes.byref(self._h)))
         self.device_id = device_id
         self.vres = None
+        contract = contract or DEFAULT_CONTRACT
+        if contract:
+            self.set_contract(contract)
 
     @property
     def num_devices(self):
@@ -322,16 +347,25 @@ class Context:
         check(lib().rm_unpin_host_buffer(self._h, array.ctypes.data))
 
     def render_frame_into(self, opts_array, mc_array, n, pixels, argb):
-        """render_frame() into caller-owned arrays (e.g. pinned ones): no allocation per frame."""
+        """render_frame() into caller-owned arrays (e.g. pinned ones): the frame's outputs are not
+        allocated per call (the 544-byte records are still marshalled per call)."""
         iters = len(bytes(opts_array)) // OPTS_BYTES
+        n = int(n)
+        if iters < 1 or np.asarray(mc_array).size != iters * TABLE_FLOATS:
+            raise ValueError(f"mc_array must hold {iters} tables of {TABLE_FLOATS} floats")
+        if pixels is not None and np.asarray(pixels).size < 4 * n:
+            raise ValueError(f"pixels holds {np.asarray(pixels).size} floats, the frame needs {4 * n}")
+        if argb is not None and np.asarray(argb).size < n:
+            raise ValueError(f"argb holds {np.asarray(argb).size} words, the frame needs {n}")
         check(lib().rm_render_frame(self._h, self._opts(opts_array, iters), _np(mc_array, np.float32, "mc_array"), iters,
                                     n, _np(pixels, np.float32, "pixels") if pixels is not None else None,
                                     _np(argb, np.uint32, "argb") if argb is not None else None))
 
     def set_contract(self, contract):
-        """"cpu" (default): the results of an OpenCL CPU device on x86-64 (checked against the CPU
-        oracle); "gfx950": the results of the reference kernel built by ROCm's OpenCL compiler for
-        this GPU (include/raymarch_hip.h rm_set_contract)."""
+        """"gfx950" (default): the results of the reference kernel built by ROCm's OpenCL compiler for
+        this GPU with -ffp-contract=off and correctly rounded divide/sqrt (checked bit for bit against
+        that build); "cpu": the results of an OpenCL CPU device on x86-64 (checked against the CPU
+        oracle) -- include/raymarch_hip.h rm_set_contract."""
         check(lib().rm_set_contract(self._h, {"cpu": 0, "gfx950": 1}[contract]))
 
     def set_seed_cast(self, mode):

@@ -50,7 +50,7 @@ def update_render_option_buffer(buffers, opts):
 
 
 def init_renderer(width, height, vres, iter=1, vname=None, voxels=None, mc_seed=1000, device=0,
-                  contract="cpu", **args):
+                  contract="gfx950", **args):
     """Build the render state: option records, one scatter table per pass, the
     device context with the volume resident in HBM, and the pipeline
     (core.clj:119-148)."""
@@ -63,8 +63,7 @@ def init_renderer(width, height, vres, iter=1, vname=None, voxels=None, mc_seed=
     else:
         vres3 = (vres,) * 3 if isinstance(vres, int) else tuple(vres)
         voxels = np.ascontiguousarray(voxels).view(np.uint8).reshape(-1)
-    ctx = _native.Context(device)
-    ctx.set_contract(contract)
+    ctx = _native.Context(device, contract=contract)
     ctx.set_volume(voxels, vres3)
     state = {
         "ctx": ctx,

@@ -102,7 +102,7 @@ struct rm_ctx {
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
-  int contract = 0;          // rm_set_contract: RM_CONTRACT_CPU_DEVICE (default) / RM_CONTRACT_GFX950
+  int contract = RM_CONTRACT_GFX950;  // rm_set_contract: RM_CONTRACT_GFX950 (default) / RM_CONTRACT_CPU_DEVICE
   // records validated by rm_check_device_opts
   std::vector<RmOpts> dev_recs;
   std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
@@ -363,7 +363,7 @@ extern "C" {
 int rm_host_fail_(int code, const char* msg) { return fail(code, "%s", msg); }
 
 const char* rm_last_error(void) { return g_err; }
-int rm_abi_version(void) { return 2; }
+int rm_abi_version(void) { return 3; }  // 3: rm_ctx defaults to RM_CONTRACT_GFX950
 
 int rm_device_count(void) {
   int n = 0;
@@ -861,6 +861,10 @@ static int render_frame_multi(rm_ctx* c, const void* opts_array, const float* mc
                               uint32_t* argb_out, bool sdf) {
   int rc = upload_frame_inputs(c, opts_array, mc_array, iter);
   if (rc) return rc;
+  // the peers' record / table buffers are overwritten with THIS call's inputs below: a later
+  // rm_frame_device_full with the pointers it used before must replicate again
+  c->repl_opts = nullptr;
+  c->repl_mc = nullptr;
   if (pixels_out) HIP_TRY(c->pix_buf.reserve((size_t)n * 16));
   if (argb_out) HIP_TRY(c->argb_buf.reserve((size_t)n * 4));
   return frame_multi_device(c, static_cast<const RmOpts*>(c->opts_buf.p), static_cast<const float*>(c->mc_buf.p), true,

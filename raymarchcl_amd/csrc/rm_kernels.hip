@@ -481,3 +481,17 @@ hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, 
 }
 
 }  // namespace rmk
+
+#if RM_STATS
+// measurement build only (tools/wave_stats.py): read / reset the event counts of rm_shade.hpp
+extern "C" int rm_debug_stats(unsigned long long* out, int n, int reset) {
+  if (n > 256) n = 256;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rmk::rm_stats_dev), sizeof(unsigned long long) * n) != hipSuccess) return -2;
+  if (reset) {
+    static unsigned long long zeros[256];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rmk::rm_stats_dev), zeros, sizeof(zeros)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif

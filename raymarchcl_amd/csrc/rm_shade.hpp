@@ -22,6 +22,48 @@ struct Counters {
 
 struct Material { v3 albedo; float r0, smoothness; };
 
+// -DRM_STATS=1: wave-level / lane-level event counts of the accelerated frame kernel (a measurement
+// build, tools/wave_stats.py; never the product).  Index = event * 5 + context
+// (0 primary march, 1 reflection march, 2 AO probe, 3 shadow march, 4 repeat of a cut turn).
+#ifndef RM_STATS
+#define RM_STATS 0
+#endif
+#ifndef RM_JCAP
+#define RM_JCAP 0
+#endif
+#ifndef RM_X_FMAJUMP
+#define RM_X_FMAJUMP 0
+#endif
+#ifndef RM_ADDS
+#define RM_ADDS 0
+#endif
+#ifndef RM_BOXDIV
+#define RM_BOXDIV 0
+#endif
+#if RM_STATS
+__device__ unsigned long long rm_stats_dev[256];
+enum { ST_EST_W, ST_EST_L, ST_BOX_L, ST_WALK_W, ST_WALK_L, ST_TRIP_W, ST_TRIP_L, ST_GO_L, ST_J_L, ST_JMAX_W,
+       ST_ADDIT_W, ST_HIT_W, ST_HIT_L, ST_ROUND_W, ST_ROUND_L, ST_FILT_W, ST_FILT_L, ST_MARCH_W, ST_MARCH_L,
+       ST_PHASE_W, ST_TASK_L, ST_PROUND_W, ST_J1_L, ST_J3_L, ST_JMAX8_W, ST_JMAX16_W };
+RM_DEV void stat_add(int ev, int ctx, unsigned long long v) {  // by the first active lane
+  const unsigned long long act = __ballot(1);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&rm_stats_dev[ev * 5 + ctx], v);
+}
+RM_DEV void stat_wave(int ev, int ctx) { stat_add(ev, ctx, 1ull); }
+RM_DEV void stat_lanes(int ev, int ctx) { stat_add(ev, ctx, (unsigned long long)__popcll(__ballot(1))); }
+RM_DEV void stat_count(int ev, int ctx, bool c) { stat_add(ev, ctx, (unsigned long long)__popcll(__ballot(c))); }
+RM_DEV int stat_max(int v) {  // max over the active lanes, 0 <= v < 4096
+  int m = 0;
+  for (int b = 11; b >= 0; b--) if (__ballot(v >= (m | (1 << b)))) m |= 1 << b;
+  return m;
+}
+RM_DEV void stat_sum(int ev, int ctx, int v) {  // sum over the active lanes, 0 <= v < 4096
+  unsigned long long t = 0;
+  for (int b = 0; b < 12; b++) t += (unsigned long long)__popcll(__ballot((v >> b) & 1)) << b;
+  stat_add(ev, ctx, t);
+}
+#endif
+
 // Everything a sample needs that is uniform across the launch.
 struct Scene {
   const uint8_t* __restrict__ vox;
@@ -55,10 +97,18 @@ RM_DEV Material material_of(const RmOpts& o, int id, bool* oob = nullptr) {
 // slab test: renderer.cl:153-161
 template <class M>
 RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
+#if RM_BOXDIV  // the two quotients of an axis share their divisor (rmd::div_by == IEEE division, bit for bit)
+  const rmd::Divisor bx = rmd::make_divisor(d.x), by = rmd::make_divisor(d.y), bz = rmd::make_divisor(d.z);
+  const float lox = rmd::div_by(o.voxelBoundsMin[0] - p.x, bx), loy = rmd::div_by(o.voxelBoundsMin[1] - p.y, by),
+              loz = rmd::div_by(o.voxelBoundsMin[2] - p.z, bz);
+  const float hix = rmd::div_by(o.voxelBoundsMax[0] - p.x, bx), hiy = rmd::div_by(o.voxelBoundsMax[1] - p.y, by),
+              hiz = rmd::div_by(o.voxelBoundsMax[2] - p.z, bz);
+#else
   const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
               loz = (o.voxelBoundsMin[2] - p.z) / d.z;
   const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
               hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
+#endif
   const float nx = M::fmin(hix, lox), ny = M::fmin(hiy, loy), nz = M::fmin(hiz, loz);
   const float a = M::fmax(M::fmax(nx, 0.0f), M::fmax(ny, nz));
   const float fx = M::fmax(hix, lox), fy = M::fmax(hiy, loy), fz = M::fmax(hiz, loz);
@@ -147,7 +197,11 @@ struct WalkTab {
 };
 template <class M, int LAYOUT>
 RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 delta, float inv_s, float c0,
-                     int* cell_out, unsigned long long table_off) {
+                     int* cell_out, unsigned long long table_off
+#if RM_STATS
+                     , int sctx
+#endif
+                     ) {
   int d, j;
   unsigned cell;
   if (LAYOUT == 2) {
@@ -161,10 +215,25 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
     cell = ((((unsigned)qz << tab.sh) | (unsigned)qy) << tab.sh) | (unsigned)qx;
     d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell + (unsigned)table_off, 0, 0);
     j = max((int)__builtin_fmaf((float)d, inv_s, c0), 1);
+#if RM_JCAP
+    j = min(j, RM_JCAP);  // (exact: a shorter skip is always valid)
+#endif
     *cell_out = (int)cell;
     // one decision per sample: hit / go on / end
     const bool hit = ok & (d == 0);
     const bool go = ok & (d != 0) & (j < steps);
+#if RM_STATS
+    stat_wave(ST_TRIP_W, sctx); stat_lanes(ST_TRIP_L, sctx); stat_count(ST_GO_L, sctx, go);
+    {
+      const int jj = go ? j : 0;
+      stat_sum(ST_J_L, sctx, jj);
+      const int jm = stat_max(jj);
+      stat_add(ST_JMAX_W, sctx, (unsigned long long)jm);
+      stat_add(ST_ADDIT_W, sctx, (unsigned long long)(jm > 1 ? (jm - 1) / 4 : 0));
+      stat_count(ST_J1_L, sctx, go & (j == 1)); stat_count(ST_J3_L, sctx, go & (j <= 3));
+      stat_add(ST_JMAX8_W, sctx, jm > 8 ? 1ull : 0ull); stat_add(ST_JMAX16_W, sctx, jm > 16 ? 1ull : 0ull);
+    }
+#endif
     if (!go) return hit ? 1 : 2;
   } else {
     const int qx = M::cell(p.x * (float)o.voxelRes[0]);
@@ -200,8 +269,53 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
   // adds per skipped sample are cheaper than its bookkeeping and failure path.)
   // (on average 5 samples are advanced per fetch: the adds are unrolled by four so that
   //  the loop bookkeeping does not cost more than the adds themselves)
+#if RM_X_FMAJUMP  // INEXACT timing probe: what a closed-form jump could be worth at most
+  p = V(__builtin_fmaf((float)j, delta.x, p.x), __builtin_fmaf((float)j, delta.y, p.y), __builtin_fmaf((float)j, delta.z, p.z));
+  steps -= j;
+  return 0;
+#endif
   p = p + delta;
   int k = j - 1;
+#if RM_ADDS == 1  // pairs + one
+  while (k >= 2) {
+    p = p + delta;
+    p = p + delta;
+    k -= 2;
+  }
+  if (k & 1) p = p + delta;
+#elif RM_ADDS == 2  // fours, then the rest as real branches (an empty asm keeps the compiler from turning them into selects)
+  while (k >= 4) {
+    p = p + delta;
+    p = p + delta;
+    p = p + delta;
+    p = p + delta;
+    k -= 4;
+  }
+  if (k & 2) {
+    asm volatile("");
+    p = p + delta;
+    p = p + delta;
+  }
+  if (k & 1) {
+    asm volatile("");
+    p = p + delta;
+  }
+#elif RM_ADDS == 3  // one sample per turn
+  while (k > 0) {
+    p = p + delta;
+    k -= 1;
+  }
+#elif RM_ADDS == 4  // pairs, the odd one as a real branch
+  while (k >= 2) {
+    p = p + delta;
+    p = p + delta;
+    k -= 2;
+  }
+  if (k & 1) {
+    asm volatile("");
+    p = p + delta;
+  }
+#else
   while (k >= 4) {
     p = p + delta;
     p = p + delta;
@@ -214,6 +328,7 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
     p = p + delta;
   }
   if (k & 1) p = p + delta;
+#endif
   steps -= j;
   return 0;
 }
@@ -247,6 +362,9 @@ struct Tracer {
   // lanes of a wavefront hand AO probes and shadow rays to each other (shade_wave()).
   float* lds_ = nullptr;
   WalkTab tab_;  // the skip tables as walk_step reads them (uniform)
+#if RM_STATS
+  int sctx_ = 0;
+#endif
   RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {
     tab_.dist8 = s.dist;
     tab_.sh = s.log2res;
@@ -448,6 +566,9 @@ struct Tracer {
                      (rpos.y - o.voxelBoundsMin[1] > m) & (o.voxelBoundsMax[1] - rpos.y > m) &
                      (rpos.z - o.voxelBoundsMin[2] > m) & (o.voxelBoundsMax[2] - rpos.z > m);
     }
+#if RM_STATS
+    if (ACCEL) { stat_wave(ST_EST_W, sctx_); stat_lanes(ST_EST_L, sctx_); stat_count(ST_BOX_L, sctx_, !known_inside); }
+#endif
     const float t_in = known_inside ? 0.0f : box_entry(rpos, dir);
     if (t_in >= 0.0f && t_in < rd) {
       const float sf = (float)steps * 0.5f;
@@ -490,9 +611,17 @@ struct Tracer {
         // others and all hits are then evaluated together (inside the loop the compiler
         // runs the hit code once per trip in which any lane finishes)
         int cell = 0, r;
+#if RM_STATS
+        stat_wave(ST_WALK_W, sctx_); stat_lanes(ST_WALK_L, sctx_);
+        do {
+          r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off, sctx_);
+        } while (r == 0);
+        stat_wave(ST_HIT_W, sctx_); stat_count(ST_HIT_L, sctx_, r == 1);
+#else
         do {
           r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off);
         } while (r == 0);
+#endif
         if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
@@ -629,13 +758,22 @@ struct Tracer {
     const float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
+#if RM_STATS
+    if (ACCEL) { stat_wave(ST_MARCH_W, sctx_); stat_lanes(ST_MARCH_L, sctx_); }
+#endif
     for (;;) {
       float g = 0.0f;
       why = 2;
+#if RM_STATS
+      if (ACCEL) { stat_wave(ST_ROUND_W, sctx_); stat_lanes(ST_ROUND_L, sctx_); }
+#endif
       if (maxSteps > 0) {
         // one exit: a turn either continues (filtered, not converged, turns left) or not
         bool nw, go;
         do {
+#if RM_STATS
+          if (ACCEL) { stat_wave(ST_FILT_W, sctx_); stat_lanes(ST_FILT_L, sctx_); }
+#endif
           maxSteps--;
           last_t = dist;
           const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
@@ -671,7 +809,14 @@ struct Tracer {
       r.pos = muladd(rdir, last_t, ro);
       if (ACCEL && !distance_only && last_kind == 1 && cut_last) {
         float sd2, sc2;
+#if RM_STATS
+        const int keep_ctx = sctx_;
+        sctx_ = 4;
+#endif
         scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
+#if RM_STATS
+        sctx_ = keep_ctx;
+#endif
       }
       if (last_kind == 0) {  // renderer.cl:211-212 for the ground / sky term
         const float h = (rdir.y * last_t + ro.y) + o.groundY;
@@ -924,8 +1069,15 @@ struct Tracer {
     }
     wave_sync();
     const int tasks = np * dl.owners;
+#if RM_STATS
+    sctx_ = 2;
+    stat_wave(ST_PHASE_W, 2); stat_add(ST_TASK_L, 2, (unsigned long long)tasks);
+#endif
     for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
       const int t = base + dl.my_slot;
+#if RM_STATS
+      stat_wave(ST_PROUND_W, 2);
+#endif
       if (t < tasks) {
         int probe, rank;
         divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
@@ -987,8 +1139,15 @@ struct Tracer {
       tasks += __popcll(mk);
     }
     wave_sync();
+#if RM_STATS
+    sctx_ = 3;
+    stat_wave(ST_PHASE_W, 3); stat_add(ST_TASK_L, 3, (unsigned long long)tasks);
+#endif
     for (int base = 0; base < tasks; base += dl.helpers) {
       const int t = base + dl.my_slot;
+#if RM_STATS
+      stat_wave(ST_PROUND_W, 3);
+#endif
       if (t < tasks) {
         const int e = task_of[t];
         const int light = e >> 6, owner = e & 63;
@@ -1092,6 +1251,9 @@ struct Tracer {
   RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
     const RmOpts& o = *sc.o;
     Hit h{};
+#if RM_STATS
+    sctx_ = 0;
+#endif
     if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
     const bool hit = live && !(h.distance >= o.maxDist);
     v3 norm = V(0.f, 0.f, 0.f);
@@ -1113,6 +1275,9 @@ struct Tracer {
       for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
         if (__ballot(alive) == 0) break;         // uniform
         v3 from = V(0.f, 0.f, 0.f);
+#if RM_STATS
+        sctx_ = 1;
+#endif
         if (alive) {
           dir = reflect(dir, rh.normal);
           from = muladd(dir, 0.0075f, rh.pos);

@@ -117,7 +117,7 @@ class FrameRenderer:
     """
 
     def __init__(self, vox, vres, opts_bytes, mc, n, width, rank=0, world=1, device=None,
-                 want_pixels=True, want_argb=True, group=None, frames_in_flight=1, contract="cpu"):
+                 want_pixels=True, want_argb=True, group=None, frames_in_flight=1, contract=None):
         import torch
 
         from . import _native
@@ -152,7 +152,8 @@ class FrameRenderer:
             # caller's stream may share one with them (two slots on one queue do not overlap).
             stream = torch.cuda.current_stream(dev) if nslots == 1 else torch.cuda.Stream(dev)
             slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb, world)
-            slot.ctx.set_contract(contract)
+            if contract:  # None: _native.DEFAULT_CONTRACT, else the library default (RM_CONTRACT_GFX950)
+                slot.ctx.set_contract(contract)
             if i == 0 or not self.shared_tables:
                 slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
             else:

@@ -43,9 +43,20 @@ def native():
 
 @pytest.fixture(scope="session")
 def gpu_ctx(native):
-    ctx = native.Context(0)  # raises loudly when there is no gfx950 device
+    ctx = native.Context(0, contract="cpu")  # raises loudly when there is no gfx950 device; shared by the CPU-oracle checks
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def cpu_contract(native):
+    """Contexts created without an explicit contract render in the CPU-device contract for the
+    duration of the test (the library's own default is RM_CONTRACT_GFX950): what the modules that
+    check against the CPU oracle need."""
+    old = native.DEFAULT_CONTRACT
+    native.DEFAULT_CONTRACT = "cpu"
+    yield
+    native.DEFAULT_CONTRACT = old
 
 
 def load_golden(name):

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Record the outputs of the reference kernel BUILT FOR gfx950 (strict build) -- run on a GPU box.
+
+The checker of the device arithmetic contract is oracle/_ref/renderer_gfx950_strict.hsaco: the unmodified
+/root/reference/resources/renderer.cl compiled by oracle/Makefile (`make -C oracle ref_gfx950`:
+clang -x cl -target amdgcn-amd-amdhsa -mcpu=gfx950 -ffp-contract=off
+-cl-fp32-correctly-rounded-divide-sqrt, linked by the clang driver against ROCm's own OpenCL
+library).  That file is git-ignored; this script runs it on the GPU exactly as core.clj:76-97 sequences
+the kernels (oracle/ref_gfx950_runner.cpp) and stores DATA ONLY:
+
+  <scene>.npz    every scene of tests/scenes.py and config 1 at full size: float32 accumulator after all
+                 passes, ARGB words, sha256 of the inputs (volume, records, scatter tables, n)
+  digests.json   the large frames (BASELINE configs 2-5, the pass-packed frames of
+                 tests/test_gpu_device_contract.py): sha256 of accumulator and ARGB buffer;
+  digest_samples.npz  every 997th pixel's bit patterns of those frames
+
+    gpurun -- 'python tests/golden/make_golden_gfx950.py gpurun_out/golden_gfx950'   # then copy into
+    tests/golden/gfx950_strict/ (gpurun only brings gpurun_out/ back)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bench  # noqa: E402
+import gfx950_pin as pin  # noqa: E402
+import oracle  # noqa: E402
+import scenes  # noqa: E402
+
+PASS_PACKED = [(8, "3"), (16, "4"), (12, "4"), (25, "4")]  # tests/test_gpu_device_contract.py
+
+
+def pass_packed_scene(passes):
+    return scenes.build(dict(vol="gyroid", vres=64, w=56, h=40, iter=passes, mat="metal", theta=-30, dist=2.2, dof=0.02),
+                        mc_seed=500)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else pin.FIXED
+    os.makedirs(out, exist_ok=True)
+    oracle.build(ref=False)
+    assert oracle.have_gfx950_ref("strict"), "oracle/_ref/renderer_gfx950_strict.hsaco is not here"
+
+    def full(key, vox, opts, mc, n):
+        px, argb, ms = oracle.gfx950_render_frame(vox, opts, mc, n, build="strict")
+        np.savez_compressed(os.path.join(out, key + ".npz"), pixels=px, argb=argb,
+                            inputs=np.array(pin.input_digest(vox, opts, mc, n)), n=np.int32(n))
+        print(f"{key:18s} n={n:8d} ref {ms:9.2f} ms  sha {pin.sha(px)[:12]}", flush=True)
+
+    for name in scenes.SCENES:
+        sc = scenes.build(name)
+        full(name, sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    wl = bench.WORKLOADS["c1"]
+    vox, vres, opts, mc = bench.build_inputs(wl)
+    full("c1", vox, opts, mc, wl["w"] * wl["h"])
+
+    digests, samples = {}, {}
+
+    def digest(key, vox, opts, mc, n):
+        px, argb, ms = oracle.gfx950_render_frame(vox, opts, mc, n, build="strict")
+        digests[key] = dict(inputs=pin.input_digest(vox, opts, mc, n), n=int(n), pixels_sha=pin.sha(px),
+                            argb_sha=pin.sha(argb))
+        samples[key] = px.view(np.uint32).reshape(-1, 4)[::pin.SAMPLE_STRIDE].reshape(-1).copy()
+        print(f"{key:18s} n={n:8d} ref {ms:9.2f} ms  sha {digests[key]['pixels_sha'][:12]}", flush=True)
+
+    for passes, _pack in PASS_PACKED:
+        sc = pass_packed_scene(passes)
+        digest(f"pass_packed_{passes}", sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    for cfg in ("c2", "c3", "c4", "c5"):
+        wl = bench.WORKLOADS[cfg]
+        vox, vres, opts, mc = bench.build_inputs(wl)
+        digest(cfg, vox, opts, mc, wl["w"] * wl["h"])
+    json.dump(digests, open(os.path.join(out, "digests.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(out, "digest_samples.npz"), **samples)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""The committed recordings of the reference kernel built for gfx950 (tests/golden/gfx950_strict/,
+made on the GPU by tests/golden/make_golden_gfx950.py) are well formed and belong to the inputs the
+GPU tests rebuild from seeds.  CPU only: the comparison of the product against them is in
+tests/test_gpu_device_contract.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gfx950_pin as pin
+import scenes
+
+
+@pytest.mark.parametrize("name", list(scenes.SCENES))
+def test_scene_recordings_belong_to_the_scenes(name):
+    sc = scenes.build(name)
+    z = np.load(os.path.join(pin.FIXED, name + ".npz"))
+    assert str(z["inputs"]) == pin.input_digest(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    px, argb = z["pixels"], z["argb"]
+    assert px.dtype == np.float32 and px.size == 4 * sc["n"] and argb.dtype == np.uint32 and argb.size == sc["n"]
+    p = px.reshape(-1, 4)
+    assert np.isfinite(p).all() and (p[:, 3] == 1.0).all() and (argb >> 24 == 0xff).all()
+
+
+def test_recordings_differ_from_the_cpu_contract(oracle_mod):
+    """The two contracts are different functions (seed casts, fma): a recording that equalled the CPU
+    oracle would have been made with the wrong checker."""
+    sc = scenes.build("orange_dof_2spp")
+    z = np.load(os.path.join(pin.FIXED, "orange_dof_2spp.npz"))
+    want_cpu, _ = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    diff = (z["pixels"].view(np.uint32) != want_cpu.view(np.uint32)).reshape(-1, 4).any(axis=1).mean()
+    assert 0.01 < diff < 0.9
+    # ... but the same picture: most pixels within 1e-4
+    a, b = z["pixels"].reshape(-1, 4)[:, :3].astype(np.float64), want_cpu.reshape(-1, 4)[:, :3].astype(np.float64)
+    rel = (np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)).max(axis=1)
+    assert (rel <= 1e-4).mean() > 0.6
+
+
+def test_digest_entries_and_samples():
+    d = json.load(open(os.path.join(pin.FIXED, "digests.json")))
+    s = np.load(os.path.join(pin.FIXED, "digest_samples.npz"))
+    assert set(d) == set(s.files) == {"pass_packed_8", "pass_packed_16", "pass_packed_12", "pass_packed_25", "c2", "c3", "c4", "c5"}
+    for k, e in d.items():
+        assert len(e["pixels_sha"]) == 64 and len(e["argb_sha"]) == 64 and len(e["inputs"]) == 64
+        assert s[k].dtype == np.uint32 and s[k].size == 4 * len(range(0, e["n"], pin.SAMPLE_STRIDE))
+    import bench
+
+    wl = bench.WORKLOADS["c2"]
+    vox, vres, opts, mc = bench.build_inputs(wl)
+    assert d["c2"]["inputs"] == pin.input_digest(vox, opts, mc, wl["w"] * wl["h"])

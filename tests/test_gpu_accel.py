@@ -7,7 +7,7 @@ import pytest
 
 import scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
 
 @pytest.mark.parametrize("kind,vres,iso", [("gyroid", 64, 32), ("gyroid-crop", (64, 40, 48), 32),

@@ -14,7 +14,7 @@ import pytest
 
 import scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -79,3 +79,38 @@ def test_device_resident_frames_over_the_devices_of_a_context(native, oracle_mod
         ctx.synchronize()
         want2, _ = oracle_mod.render_frame(sc["vox"], sc["opts"], mc2, n)
         assert np.array_equal(px.cpu().numpy().view(np.uint32), want2.view(np.uint32))
+
+
+def test_host_and_device_frames_interleaved_on_a_multi_device_context(native, oracle_mod):
+    """rm_frame_device_full -> rm_render_frame (other records and tables, host buffers) ->
+    rm_frame_device_full with the first call's pointers: the host call overwrites the other devices'
+    copies of the records and tables, so the third call must replicate again."""
+    import torch
+
+    sc = scenes.build("orange_dof_2spp")
+    n, it = sc["n"], sc["iter"]
+    want_px, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], n)
+    other = scenes.build("orange_dof_2spp", mc_seed=77)
+    opts2 = bytearray(other["opts"])
+    opts2[260:264] = np.float32(1.25).tobytes()  # another exposure in record 0 (Appendix A: offset 260)
+    opts2[544 + 260:544 + 264] = np.float32(1.25).tobytes()
+    want2, _ = oracle_mod.render_frame(sc["vox"], bytes(opts2), other["mc"], n)
+    dev = torch.device("cuda", 0)
+    d_opts = torch.frombuffer(bytearray(sc["opts"]), dtype=torch.uint8).to(dev)
+    d_mc = torch.from_numpy(np.ascontiguousarray(sc["mc"], np.float32).reshape(-1)).to(dev)
+    px = torch.zeros(4 * n, dtype=torch.float32, device=dev)
+    argb = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with native.Context([0, 0, 0]) as ctx:
+        ctx.set_volume(sc["vox"], sc["vres"])
+        ctx.check_device_opts(d_opts.data_ptr(), it, n, sc["w"])
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), it, n, sc["w"], px.data_ptr(), argb.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(px.cpu().numpy().view(np.uint32), want_px.view(np.uint32))
+        got2, _ = ctx.render_frame(bytes(opts2), other["mc"], n)
+        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+        px.zero_()
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), it, n, sc["w"], px.data_ptr(), argb.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(px.cpu().numpy().view(np.uint32), want_px.view(np.uint32))
+        assert np.array_equal(argb.cpu().numpy().view(np.uint32), want_argb)

@@ -14,7 +14,7 @@ never wrong: over random rays and rays placed within a few ulps of every decisio
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
 
 def _records():

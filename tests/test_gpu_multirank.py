@@ -12,7 +12,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+from gfx950_pin import pin  # noqa: E402,F401
+
+pytestmark = pytest.mark.gpu  # ranks run in the library's default contract (gfx950): checked against the reference build / its recording
 
 
 def _free_port():
@@ -57,12 +59,12 @@ def _worker(rank, world, port, tmpdir, frames_in_flight=1, backend="gloo"):
 
 
 @pytest.mark.parametrize("world,frames_in_flight", [(2, 1), (3, 1), (2, 2)])
-def test_tile_partition_over_ranks(tmp_path, oracle_mod, world, frames_in_flight):
+def test_tile_partition_over_ranks(tmp_path, pin, world, frames_in_flight):
     import scenes
 
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), frames_in_flight), nprocs=world, join=True)
     sc = scenes.build("metal_3spp")
-    want, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    want, want_argb = pin.frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], sc["n"])
     px = np.load(tmp_path / "px.npy")
     argb = np.load(tmp_path / "argb.npy")
     assert np.array_equal(px.view(np.uint32), want.view(np.uint32))
@@ -70,7 +72,7 @@ def test_tile_partition_over_ranks(tmp_path, oracle_mod, world, frames_in_flight
 
 
 @pytest.mark.parametrize("frames_in_flight", [1, 2])
-def test_tile_partition_over_rccl(tmp_path, oracle_mod, frames_in_flight):
+def test_tile_partition_over_rccl(tmp_path, pin, frames_in_flight):
     """The same with one rank per GPU and the gather on the `nccl` backend (= RCCL over xGMI),
     side streams included -- the path bench.py --gpus N takes.  Needs >= 2 devices: runs on the
     driver's multi-GPU node, skipped on the single-GPU box."""
@@ -82,6 +84,6 @@ def test_tile_partition_over_rccl(tmp_path, oracle_mod, frames_in_flight):
     world = min(world, 8)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), frames_in_flight, "nccl"), nprocs=world, join=True)
     sc = scenes.build("metal_3spp")
-    want, want_argb = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    want, want_argb = pin.frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], sc["n"])
     assert np.array_equal(np.load(tmp_path / "px.npy").view(np.uint32), want.view(np.uint32))
     assert np.array_equal(np.load(tmp_path / "argb.npy"), want_argb)

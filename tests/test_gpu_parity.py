@@ -8,7 +8,7 @@ import pytest
 import scenes
 from conftest import load_golden
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
 NAMES = list(scenes.SCENES)
 

@@ -17,7 +17,7 @@ import pytest
 
 import scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
 
 def rel(a, b):
@@ -48,7 +48,7 @@ def rendered(request, refs, native):
     n = sc["n"]
     ref = {b: refs.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], n, build=b)[:2] for b in refs.GFX950_BUILDS}
     hip = {}
-    with native.Context(0) as ctx:
+    with native.Context(0, contract="cpu") as ctx:  # (module-scoped fixture: the per-test cpu_contract fixture is not active here)
         ctx.set_volume(sc["vox"], sc["vres"])
         for mode in ("x86", "gpu"):
             ctx.set_seed_cast(mode)

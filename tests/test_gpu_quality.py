@@ -8,7 +8,7 @@ import raymarchcl_amd as rm
 from raymarchcl_amd import generators as gen
 from raymarchcl_amd import structs
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
 
 def _records(w, h, it, vres, mat, theta, over=None):

@@ -16,7 +16,7 @@ import pytest
 
 import scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 F = np.float32
 
 

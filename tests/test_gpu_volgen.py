@@ -6,7 +6,7 @@ import pytest
 
 from oracle import volgen_np as vg
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
 
 def test_terrain_device_matches_restatement(gpu_ctx):

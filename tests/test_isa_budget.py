@@ -75,7 +75,7 @@ def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
     leftovers -> memory aperture violation; earlier in the round the same shape as wrong pixels).  No
     kernel of the library may contain that shape (tools/isa_exec_lint.py; every kernel, not only the
     bench instantiations)."""
-    import isa_exec_lint
+    from raymarchcl_amd import isa_exec_lint
 
     lines = frame_kernel_asm.split("\n")
     fatal, kernels = [], 0
@@ -106,7 +106,7 @@ def test_the_lint_recognises_the_shape_and_nothing_else():
     only entered through s_cbranch_execz, in front of the exec restore), the same with the exit reached by
     falling out of an s_cbranch_execnz loop, and two harmless neighbours (a reload after the restore; a
     reload at the end of an `if` region under the region's own mask)."""
-    import isa_exec_lint
+    from raymarchcl_amd import isa_exec_lint
 
     def kernel(body):
         return ("_Zk:\n" + body + "\n.Lfunc_end0:\n").split("\n")

@@ -17,7 +17,7 @@ procs = []
 for arg in sys.argv[1:]:
     name, _, flags = arg.partition("=")
     out = os.path.join(_native.HERE, f"libraymarch_hip_ab_{name}.so")
-    cmd = ["/opt/rocm/bin/hipcc"] + _native.HIPCC_FLAGS + flags.split() + \
+    cmd = [_native._hipcc()] + _native.HIPCC_FLAGS + flags.split() + \
           [os.path.join(_native.CSRC, s) for s in _native.SOURCES] + ["-o", out]
     procs.append((name, subprocess.Popen(cmd)))
 for name, p in procs:

@@ -92,7 +92,7 @@ def main():
         for b in oracle.GFX950_BUILDS:
             ref[b], _, ref_ms[b] = oracle.gfx950_render_frame(sc["vox"], sc["opts"], sc["mc"], n, build=b, tonemap=False)
         hip = {}
-        with _native.Context(0) as ctx:
+        with _native.Context(0, contract="cpu") as ctx:
             ctx.set_volume(sc["vox"], sc["vres"])
             for mode in ("x86", "gpu"):
                 ctx.set_seed_cast(mode)

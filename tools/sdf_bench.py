@@ -34,7 +34,7 @@ def main():
         width=w, height=h, vres=[args.res] * 3, t=i * 0.333, iter=it, eyepos=rm.compute_eyepos(-45, 2.25, 0.35),
         targetpos=[0, -0.4, 0], mat=args.mat, dof=0.025)) for i in range(it))
     mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=1000 + i) for i in range(it)])
-    with _native.Context(0) as ctx:
+    with _native.Context(0, contract="cpu") as ctx:
         ctx.set_sdf_volume(sdf, (args.res,) * 3)
         ctx.render_sdf_frame(opts, mc, w * h, want_pixels=False)
         best = 1e9
