@@ -1299,6 +1299,113 @@ struct Tracer {
     return atmosphere(s, ro, rdir, h.distance, col);
   }
 
+  // =====================================================================================
+  // The frame as TWO launches (rm_kernels.hip: march kernel, then light kernel).
+  //
+  // The chain of marches of a sample -- primary ray, then up to reflectIter mirror bounces -- never
+  // looks at a lighting result (renderer.cl:426-438: the next bounce starts from the hit's position
+  // and normal, the colours are only summed), so it can run first for every sample and leave one
+  // record per hit in HBM: position, normal (the perturbed one for the primary hit), distance, object
+  // code = 8 floats, the 64 lanes of a wavefront side by side.  The light kernel re-derives the sample
+  // (sample_init / camera_dir: the same code on the same inputs) and the bounce directions
+  // (reflect / muladd of recorded values: the same operations), runs the wave-shared phases of
+  // lighting_wave() for every recorded hit and blends.  Per sample the operations and their order are
+  // those of sample_colour_wave(), so the bits are too; what changes is that neither kernel carries
+  // the other's state through its loops.
+  // =====================================================================================
+  static constexpr int kRecFloats = 8;
+  RM_DEV static void rec_store(float* rec, int hit, v3 pos, v3 nrm, float distance, int objectID) {
+    float* r = rec + (size_t)hit * kRecFloats * 64;
+    r[0 * 64] = pos.x; r[1 * 64] = pos.y; r[2 * 64] = pos.z;
+    r[3 * 64] = nrm.x; r[4 * 64] = nrm.y; r[5 * 64] = nrm.z;
+    r[6 * 64] = distance;
+    r[7 * 64] = __int_as_float(objectID);
+  }
+  RM_DEV static void rec_load(const float* rec, int hit, v3& pos, v3& nrm, float& distance, int& objectID) {
+    const float* r = rec + (size_t)hit * kRecFloats * 64;
+    pos = V(r[0 * 64], r[1 * 64], r[2 * 64]);
+    nrm = V(r[3 * 64], r[4 * 64], r[5 * 64]);
+    distance = r[6 * 64];
+    objectID = __float_as_int(r[7 * 64]);
+  }
+  // march kernel: everything of sample_colour_wave() that is a march
+  RM_DEV void trace_chain(int id, bool live, float* rec) {
+    const RmOpts& o = *sc.o;
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    Hit h{};
+    if (live) march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
+    const bool hit = live && !(h.distance >= o.maxDist);
+    v3 norm = V(0.f, 0.f, 0.f);
+    float r0 = 0.0f;
+    if (hit) {
+      const Material m = material(h.objectID);
+      const float k = 1.0f / M::mad(m.smoothness, 200.0f, 5.0f);
+      norm = mads(s.mcNormal, k, h.normal);
+      r0 = m.r0;
+    }
+    rec_store(rec, 0, h.pos, norm, h.distance, h.objectID);
+    bool alive = hit && r0 > 0.0f && o.reflectIter > 0;
+    Hit rh{};
+    rh.pos = h.pos;
+    rh.normal = norm;
+    v3 dir = rdir;
+    for (int i = 0; i < o.reflectIter; i++) {
+      if (__ballot(alive) == 0) break;  // uniform
+      if (alive) {
+        dir = reflect(dir, rh.normal);
+        const v3 from = muladd(dir, 0.0075f, rh.pos);
+        march(from, dir, rh, o.maxDist, o.maxIter, false);
+        rec_store(rec, i + 1, rh.pos, rh.normal, rh.distance, rh.objectID);
+        if (rh.objectID < 0) alive = false;
+        else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
+      }
+    }
+  }
+  // light kernel: sample_colour_wave() with the marches read back
+  RM_DEV v3 shade_from_records(int id, float* lds, bool live, const float* rec) {
+    lds_ = lds;
+    const RmOpts& o = *sc.o;
+    const Sample s = sample_init(id);
+    const v3 rdir = camera_dir(s);
+    Hit h{};
+    v3 norm = V(0.f, 0.f, 0.f);
+    if (live) rec_load(rec, 0, h.pos, norm, h.distance, h.objectID);
+    const bool hit = live && !(h.distance >= o.maxDist);
+    float r0 = 0.0f;
+    if (hit) r0 = material(h.objectID).r0;
+    const bool bounces = hit && r0 > 0.0f && o.reflectIter > 0;
+    v3 refl = V(0.f, 0.f, 0.f);
+    if (__ballot(bounces) != 0) {  // uniform
+      Hit rh{};
+      rh.pos = h.pos;
+      rh.normal = norm;
+      v3 dir = rdir;
+      bool alive = bounces;
+      for (int i = 0; i < o.reflectIter; i++) {
+        if (__ballot(alive) == 0) break;  // uniform
+        v3 from = V(0.f, 0.f, 0.f);
+        if (alive) {
+          dir = reflect(dir, rh.normal);
+          from = muladd(dir, 0.0075f, rh.pos);
+          rec_load(rec, i + 1, rh.pos, rh.normal, rh.distance, rh.objectID);
+        }
+        const bool bhit = alive && rh.objectID >= 0;
+        const v3 lit = lighting_wave(bhit, s, dir, rh.pos, rh.objectID, rh.normal, true, V(0.f, 0.f, 0.f));
+        if (alive) {
+          const v3 col = bhit ? lit : sky(dir);
+          refl = refl + atmosphere(s, from, dir, rh.distance, col);
+          if (rh.objectID < 0) alive = false;
+          else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
+        }
+      }
+    }
+    if (hit && !bounces) refl = sky(reflect(rdir, norm));
+    const v3 lit = lighting_wave(hit, s, rdir, h.pos, h.objectID, norm, false, refl);
+    const v3 col = hit ? lit : sky(rdir);
+    return atmosphere(s, s.eye, rdir, h.distance, col) * o.exposure;
+  }
+
   // shade() through the wave-shared path; every lane of the wavefront that has a pixel
   // must call it (lanes without one have left the kernel), lds = kWaveLdsFloats floats
   RM_DEV v3 shade_wave(int id, float* lds, bool live = true) {
