@@ -236,6 +236,55 @@ def main():
     pass_ms = float(np.median(kernel_ms))  # average duration of one render-kernel launch
     serial_ms = float(np.median(serial[1:]))
 
+    # N > 1: where a frame's time goes on every rank (events on the rank's stream around its share, the
+    # gather and the root's resolve; strictly one frame at a time), and the same frame exchanged as
+    # tonemapped ARGB words instead of float4 accumulators (what a caller that wants only the image gets)
+    per_rank = argb_exchange = None
+    if world > 1:
+        rows = []
+        for _ in range(6):
+            sync_all()
+            fr.render(timed=True)
+            torch.cuda.synchronize(dev)
+            rows.append(fr.last_breakdown())
+        mine = [float(v) for v in np.median(np.array(rows[1:]), axis=0)]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        fa = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev,
+                                    want_pixels=False, want_argb=True, frames_in_flight=args.frames_in_flight,
+                                    contract=args.contract)
+        for _ in range(args.warmup):
+            fa.render()
+        sync_all()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            fa.render()
+        sync_all()
+        ta = time.perf_counter() - ta
+        arows = []
+        for _ in range(4):
+            sync_all()
+            fa.render(timed=True)
+            torch.cuda.synchronize(dev)
+            arows.append(fa.last_breakdown())
+        amine = [float(v) for v in np.median(np.array(arows[1:]), axis=0)]
+        aeveryone = [None] * world
+        dist.all_gather_object(aeveryone, amine + [ta])
+        fa.close()
+        if rank == 0:
+            def summary(rows_, k):
+                v = [r[k] for r in rows_]
+                return {"max": round(max(v), 4), "mean": round(sum(v) / len(v), 4), "by_rank": [round(x, 4) for x in v]}
+            per_rank = {"share_render_ms": summary(everyone, 0), "gather_ms": summary(everyone, 1),
+                        "resolve_ms_root": round(everyone[0][2], 4),
+                        "note": "one frame at a time; gather_ms is the collective as the rank's stream sees it: on the root "
+                                "it ends when the slowest rank's tiles have arrived, on the others when theirs are sent"}
+            argb_exchange = {"ms_per_step": round(max(r[3] for r in aeveryone) / args.steps * 1e3, 4),
+                             "share_render_ms": summary(aeveryone, 0), "gather_ms": summary(aeveryone, 1),
+                             "resolve_ms_root": round(aeveryone[0][2], 4),
+                             "note": "the same frames with want_pixels=False: every rank tonemaps its tiles, 4 B per pixel "
+                                     "are gathered instead of 16, the root un-permutes (rm_frame_device_argb)"}
+
     out = None
     if rank == 0:
         samples_per_frame = n * spp
@@ -286,6 +335,9 @@ def main():
                 "table_reads_per_sample": round(c["mc_reads"] / samples_per_frame, 2),
             },
         }
+        if per_rank:
+            out["per_rank"] = per_rank
+            out["argb_exchange"] = argb_exchange
         if world == 1:
             # the same frame through the host-buffer boundary (rm_render_frame: tables +
             # records up, float4 accumulator + ARGB back over PCIe) -- never `value`
@@ -412,6 +464,17 @@ def library_bench(args):
         serial.append((time.perf_counter() - ts) * 1e3)
         ms, launches = ctx.last_frame_timing()  # the root's partition
         kms.append(ms / launches)
+    shares, frame_ms = ctx.last_frame_breakdown()
+    # the same frames with only the ARGB image wanted: tonemapped words cross the links (4 B per pixel)
+    for _ in range(args.warmup):
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), spp, n, width, None, d_argb.data_ptr())
+    ctx.synchronize()
+    ta = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), spp, n, width, None, d_argb.data_ptr())
+    ctx.synchronize()
+    ta = time.perf_counter() - ta
+    ashares, aframe_ms = ctx.last_frame_breakdown()
     ctx.close()
     alg_frame, c = algorithmic_bytes(vox, vres, opts, mc, n, spp)
     world = len(ids)
@@ -433,6 +496,15 @@ def library_bench(args):
                      "kernel": "render_frame_kernel (the root device's partition)", "kernel_ms": round(pass_ms, 4),
                      "launches_per_frame": launches, "alg_bytes_per_launch": int(alg_frame / launches / world),
                      "alg_bytes_per_sample": round(alg_frame / (n * spp), 1)},
+        "per_rank": {"share_render_ms": {"max": round(max(shares), 4), "mean": round(sum(shares) / len(shares), 4),
+                                         "by_rank": [round(v, 4) for v in shares]},
+                     "frame_ms_root": round(frame_ms, 4),
+                     "note": "device time of the last frame: each device's partition kernels; frame_ms_root = start of the "
+                             "root's share to the end of its resolve (waits for the slowest device + peer copies + resolve)"},
+        "argb_exchange": {"ms_per_step": round(ta / args.steps * 1e3, 4),
+                          "share_render_ms": {"max": round(max(ashares), 4), "mean": round(sum(ashares) / len(ashares), 4)},
+                          "frame_ms_root": round(aframe_ms, 4),
+                          "note": "d_pixels = NULL: every device tonemaps its tiles, 4 B per pixel are peer-copied instead of 16"},
     }
     print(json.dumps(out), flush=True)
     return 0

@@ -225,6 +225,17 @@ int rm_render_sdf_frame(rm_ctx* ctx, const void* opts544_array, const float* mc_
 int rm_tiles_per_part(int resx, int n, int parts);
 int rm_frame_device(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
                     int width, int tile_first, int tile_stride, float* d_tiles);
+/* The same partition with its TonemapImage words next to the accumulators: d_argb_tiles receives, tile-major
+ * like d_tiles, TonemapImage(d_opts[0]) of the partition's pixels after the last pass (renderer.cl:496-508 is
+ * per pixel, so tonemapping before the exchange changes nothing).  A frame whose caller wants the ARGB image
+ * only exchanges these words -- 4 bytes per pixel over the links instead of 16 -- and the root un-permutes
+ * them with rm_resolve_device_argb.  d_argb_tiles: rm_tiles_per_part * 64 words. */
+int rm_frame_device_argb(rm_ctx* ctx, const void* d_opts, const float* d_mc, int iter, int n,
+                         int width, int tile_first, int tile_stride, float* d_tiles, uint32_t* d_argb_tiles);
+/* Tile-major ARGB words of `parts` partitions, gathered as [parts][tiles_per_part][64] -> the row-major
+ * ARGB image (the reference's q-buf, core.clj:91-97).  Asynchronous on the context's stream. */
+int rm_resolve_device_argb(rm_ctx* ctx, const uint32_t* d_argb_tiles_all, int parts, int n, int width,
+                           uint32_t* d_argb);
 /* The unpartitioned frame in ONE kernel launch per 16 passes (one for a 16-pass frame): all passes, blended in order, the row-major
  * float4 image into d_pixels (nullable) and TonemapImage(d_opts[0]) into d_argb (nullable;
  * at least one of the two).  Same validation contract as rm_frame_device.
@@ -260,6 +271,11 @@ int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int w
 int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
 /* Device time (HIP events) of the last build of the tables derived from the resident volume
  * (dist8 + oct8 + surf32; once per (volume, isoVal), inside the first call that needs them). */
+/* Device time of the last frame by device of the context: share_ms[r] = the render kernels of device r's
+ * tile partition (r < min(rm_num_devices, max_devices)); *frame_ms = from the start of the root's share to
+ * the end of its resolve (multi-device: includes the wait for the slowest device's tiles and the peer
+ * copies).  Measurement only; blocks until the frame is done. */
+int rm_last_frame_breakdown(rm_ctx* ctx, float* share_ms, int max_devices, float* frame_ms);
 int rm_last_table_build_ms(rm_ctx* ctx, float* ms);
 
 /* Test hook: copy out the derived structures the kernels use for the resident

@@ -53,6 +53,7 @@ EXPORTS = [
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
+    "rm_frame_device_argb", "rm_resolve_device_argb", "rm_last_frame_breakdown",
     "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims", "rm_selftest_filter",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
@@ -203,6 +204,8 @@ def lib():
     L.rm_render_sdf_frame.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
     L.rm_frame_device.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     L.rm_resolve_device.argtypes = [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]
+    L.rm_frame_device_argb.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]
+    L.rm_resolve_device_argb.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     L.rm_check_device_opts.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
     L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
@@ -446,9 +449,26 @@ class Context:
         check(lib().rm_frame_device(self._h, d_opts, d_mc, iters, n, width, tile_first, tile_stride,
                                     d_tiles))
 
+    def frame_device_argb(self, d_opts, d_mc, iters, n, width, d_tiles, d_argb_tiles, tile_first=0, tile_stride=1):
+        """frame_device() that also leaves the partition's TonemapImage words, tile-major, in d_argb_tiles
+        (the 4-byte-per-pixel exchange unit of frames that want the ARGB image only)."""
+        check(lib().rm_frame_device_argb(self._h, d_opts, d_mc, iters, n, width, tile_first, tile_stride,
+                                         d_tiles, d_argb_tiles))
+
+    def resolve_device_argb(self, d_argb_tiles_all, parts, n, width, d_argb):
+        check(lib().rm_resolve_device_argb(self._h, d_argb_tiles_all, parts, n, width, d_argb))
+
     def frame_device_full(self, d_opts, d_mc, iters, n, width, d_pixels=None, d_argb=None):
         """The unpartitioned frame, one launch per 16 passes: row-major pixels and / or ARGB; asynchronous."""
         check(lib().rm_frame_device_full(self._h, d_opts, d_mc, iters, n, width, d_pixels, d_argb))
+
+    def last_frame_breakdown(self):
+        """-> ([share_ms per device], frame_ms): rm_last_frame_breakdown."""
+        k = self.num_devices
+        shares = (ctypes.c_float * k)()
+        total = ctypes.c_float()
+        check(lib().rm_last_frame_breakdown(self._h, shares, k, ctypes.byref(total)))
+        return [float(v) for v in shares], float(total.value)
 
     def last_table_build_ms(self):
         ms = ctypes.c_float()

@@ -90,7 +90,7 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::shared_ptr<Volume> vol;
-  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, rec_buf;
+  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, rec_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
@@ -405,7 +405,7 @@ static int create_one(int device_id, rm_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_resolved, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_resolved);  // (timed: rm_last_frame_breakdown)
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b1);
   if (e != hipSuccess) {
@@ -492,7 +492,7 @@ void rm_destroy(rm_ctx* c) {
   for (const void* h : c->host_bufs) (void)hipHostUnregister(const_cast<void*>(h));
   c->host_bufs.clear();
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
-                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->rec_buf};
+                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->rec_buf, &c->atile_buf};
   for (DevBuf* b : bufs) b->release();
   c->vol.reset();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -822,7 +822,14 @@ static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc
   const int resx = recs[0].resolution[0];
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(resx, n), world);
   const size_t part_bytes = (size_t)tpp * 64 * 16;
-  HIP_TRY(c->tile_buf.reserve(part_bytes * world));
+  // A caller that wants the ARGB image only gets it exchanged as tonemapped words: every device tonemaps its
+  // own tiles in the frame kernel (TonemapImage is per pixel, renderer.cl:496-508), 4 bytes per pixel cross
+  // the links instead of 16, and the root only un-permutes.  (Quality-mode frames keep the float exchange:
+  // their ARGB comes from the root's resolve.)
+  const bool words = !d_pixels && d_argb && !sdf;
+  const size_t xfer_bytes = words ? part_bytes / 4 : part_bytes;
+  HIP_TRY(c->tile_buf.reserve(words ? part_bytes : part_bytes * world));
+  if (words) HIP_TRY(c->atile_buf.reserve(xfer_bytes * world));
   const size_t opts_bytes = (size_t)iter * RM_OPTS_BYTES, mc_bytes = (size_t)iter * RM_TABLE_FLOATS * 4;
   if (replicate) HIP_TRY(hipEventRecord(c->ev_in, c->stream));  // the root's inputs are complete here
   for (int r = 0; r < world; r++) {
@@ -841,9 +848,11 @@ static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc
       my_opts = static_cast<const RmOpts*>(d->opts_buf.p);
       my_mc = static_cast<const float*>(d->mc_buf.p);
       HIP_TRY(d->tile_buf.reserve(part_bytes));
+      if (words) HIP_TRY(d->atile_buf.reserve(xfer_bytes));
     }
     FrameOut out;
     out.acc = static_cast<float*>(r == 0 ? c->tile_buf.p : d->tile_buf.p);
+    if (words) out.argb = static_cast<uint32_t*>(d->atile_buf.p);  // (the root's partition is part 0 of its gather buffer)
     out.tile_first = r;
     out.tile_stride = world;
     int rc = frame_on_device(d, my_opts, my_mc, resx, iter, n, out, same, recs, sdf);
@@ -851,15 +860,22 @@ static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc
     if (r > 0) {
       // the root's gather buffer is free once the previous frame's resolve has read it
       if (c->resolved_once) HIP_TRY(hipStreamWaitEvent(d->stream, c->ev_resolved, 0));
-      HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(c->tile_buf.p) + part_bytes * r, c->device, d->tile_buf.p,
-                                 d->device, part_bytes, d->stream));
+      if (words)
+        HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(c->atile_buf.p) + xfer_bytes * r, c->device, d->atile_buf.p,
+                                   d->device, xfer_bytes, d->stream));
+      else
+        HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(c->tile_buf.p) + part_bytes * r, c->device, d->tile_buf.p,
+                                   d->device, part_bytes, d->stream));
       HIP_TRY(hipEventRecord(d->ev_done, d->stream));
     }
   }
   HIP_TRY(hipSetDevice(c->device));
   for (rm_ctx* p : c->peers) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_done, 0));
-  HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp, d_opts, d_pixels,
-                              d_argb, n, c->contract == RM_CONTRACT_GFX950 && !sdf));
+  if (words)
+    HIP_TRY(rmk::launch_resolve_argb(c->stream, static_cast<const uint32_t*>(c->atile_buf.p), world, tpp, resx, d_argb, n));
+  else
+    HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp, d_opts, d_pixels,
+                                d_argb, n, c->contract == RM_CONTRACT_GFX950 && !sdf));
   HIP_TRY(hipEventRecord(c->ev_resolved, c->stream));
   c->resolved_once = true;
   return RM_OK;
@@ -1036,6 +1052,35 @@ int rm_frame_device(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, 
                          c->dev_recs.data(), false);
 }
 
+int rm_frame_device_argb(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, int n, int width,
+                         int tile_first, int tile_stride, float* d_tiles, uint32_t* d_argb_tiles) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_opts || !d_mc || !d_tiles || !d_argb_tiles) return fail(RM_EINVAL, "NULL device buffer");
+  if (iter <= 0 || n <= 0 || width <= 0) return fail(RM_EINVAL, "iter = %d, n = %d, width = %d", iter, n, width);
+  if (tile_stride < 1 || tile_first < 0 || tile_first >= tile_stride)
+    return fail(RM_EINVAL, "tile partition (%d,%d)", tile_first, tile_stride);
+  rc = check_validated(c, d_opts, iter, n, width);
+  if (rc) return rc;
+  FrameOut out;
+  out.acc = d_tiles;
+  out.argb = d_argb_tiles;
+  out.tile_first = tile_first;
+  out.tile_stride = tile_stride;
+  return frame_on_device(c, static_cast<const RmOpts*>(d_opts), d_mc, width, iter, n, out, c->dev_same.data(),
+                         c->dev_recs.data(), false);
+}
+
+int rm_resolve_device_argb(rm_ctx* c, const uint32_t* d_argb_tiles_all, int parts, int n, int width, uint32_t* d_argb) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_argb_tiles_all || !d_argb) return fail(RM_EINVAL, "NULL device buffer");
+  if (parts < 1 || n <= 0 || width <= 0) return fail(RM_EINVAL, "parts = %d, n = %d, width = %d", parts, n, width);
+  const int tpp = rmk::tiles_per_part(rmk::tiles_total(width, n), parts);
+  HIP_TRY(rmk::launch_resolve_argb(c->stream, d_argb_tiles_all, parts, tpp, width, d_argb, n));
+  return RM_OK;
+}
+
 int rm_frame_device_full(rm_ctx* c, const void* d_opts, const float* d_mc, int iter, int n, int width,
                          float* d_pixels, uint32_t* d_argb) {
   int rc = check_ctx(c);
@@ -1083,6 +1128,31 @@ int rm_last_frame_timing(rm_ctx* c, float* ms, int* launches) {
   HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
   if (ms) *ms = t;
   if (launches) *launches = c->launches;
+  return RM_OK;
+}
+
+int rm_last_frame_breakdown(rm_ctx* c, float* share_ms, int max_devices, float* frame_ms) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->timed) return fail(RM_ESTATE, "no frame has been rendered");
+  const int world = 1 + (int)c->peers.size();
+  if (world > 1 && !c->resolved_once) return fail(RM_ESTATE, "no multi-device frame has been rendered");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(world > 1 ? c->ev_resolved : c->ev1));
+  for (int r = 0; r < world && r < max_devices; r++) {
+    rm_ctx* d = r == 0 ? c : c->peers[r - 1];
+    float t = 0.f;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipEventSynchronize(d->ev1));
+    HIP_TRY(hipEventElapsedTime(&t, d->ev0, d->ev1));
+    if (share_ms) share_ms[r] = t;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (frame_ms) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev0, world > 1 ? c->ev_resolved : c->ev1));
+    *frame_ms = t;
+  }
   return RM_OK;
 }
 

@@ -40,7 +40,7 @@ struct FrameLaunch {
   const RmOpts* opts_all = nullptr;  // record of the first pass of this launch (device)
   const RmOpts* opts0 = nullptr;     // record 0 of the frame (device): tonemap parameters
   float* acc = nullptr;            // float4 accumulators: tile-major [tiles_per_part][64], or the row-major image
-  uint32_t* argb = nullptr;        // row_major only, nullable: TonemapImage output, written with the last pass
+  uint32_t* argb = nullptr;        // nullable: TonemapImage output, written with the last pass (row-major image, or tile-major like acc)
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
@@ -60,6 +60,8 @@ int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
                           const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n,
                           bool device_arith = false);
+hipError_t launch_resolve_argb(hipStream_t st, const uint32_t* d_argb_tiles, int parts, int tiles_per_part, int resx,
+                               uint32_t* d_argb, int n);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
                           uint32_t* d_argb, int n, bool device_arith = false);
 // surf32 of a resident volume for hit threshold `iso` (rm_accel.hip) and -- when d_dist is not

@@ -233,7 +233,9 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   }
   if (first) {
     a.acc[at] = make_float4(px, py, pz, 1.0f);
-    if (a.argb) a.argb[id] = tonemap_argb<M>(px, py, pz, a.opts0->gamma);
+    // (row-major image: at the work-item id; a partition: tile-major next to its accumulators --
+    //  the 4-byte-per-pixel exchange unit of frames whose caller wants the ARGB image only)
+    if (a.argb) a.argb[a.row_major ? (long long)id : at] = tonemap_argb<M>(px, py, pz, a.opts0->gamma);
   }
 }
 
@@ -291,6 +293,20 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
     if (pixels) pixels[id] = p;
     using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<0>>::type;
     if (argb) argb[id] = tonemap_argb<M>(p.x, p.y, p.z, g);
+  }
+}
+
+// Tile-major ARGB words of `parts` interleaved partitions -> the row-major ARGB image (frames exchanged
+// as tonemapped words: 4 bytes per pixel over the links instead of 16).
+__global__ __launch_bounds__(256) void resolve_argb_kernel(const uint32_t* __restrict__ tiles, int parts, int tiles_per_part,
+                                                           int resx, uint32_t* __restrict__ argb, int n) {
+  const int tiles_x = (resx + kTile - 1) / kTile;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n;
+       id += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(id % resx), y = (int)(id / resx);
+    const int tile = (y >> 3) * tiles_x + (x >> 3);
+    const int lane = ((y & 7) << 3) | (x & 7);
+    argb[id] = tiles[((long long)(tile % parts) * tiles_per_part + tile / parts) * 64 + lane];
   }
 }
 
@@ -526,6 +542,15 @@ hipError_t launch_resolve(hipStream_t st, const float* tiles, int parts, int til
   else
     resolve_kernel<false><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part, d_opts0,
                                                   reinterpret_cast<float4*>(pixels), argb, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve_argb(hipStream_t st, const uint32_t* tiles, int parts, int tiles_per_part, int resx,
+                               uint32_t* argb, int n) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  resolve_argb_kernel<<<blocks, 256, 0, st>>>(tiles, parts, tiles_per_part, resx, argb, n);
   return hipGetLastError();
 }
 

@@ -40,6 +40,15 @@ struct Material { v3 albedo; float r0, smoothness; };
 #ifndef RM_BOXDIV
 #define RM_BOXDIV 0
 #endif
+#ifndef RM_AO_FAR
+#define RM_AO_FAR 0
+#endif
+#ifndef RM_UDIV
+#define RM_UDIV 0
+#endif
+#ifndef RM_PRIO
+#define RM_PRIO 0
+#endif
 #if RM_STATS
 __device__ unsigned long long rm_stats_dev[256];
 enum { ST_EST_W, ST_EST_L, ST_BOX_L, ST_WALK_W, ST_WALK_L, ST_TRIP_W, ST_TRIP_L, ST_GO_L, ST_J_L, ST_JMAX_W,
@@ -362,6 +371,9 @@ struct Tracer {
   // lanes of a wavefront hand AO probes and shadow rays to each other (shade_wave()).
   float* lds_ = nullptr;
   WalkTab tab_;  // the skip tables as walk_step reads them (uniform)
+#if RM_UDIV
+  float inv_sf_full_, inv_sf_half_;  // 1 / (steps * 0.5) for steps = maxVoxelIter and maxVoxelIter / 2 (uniform)
+#endif
 #if RM_STATS
   int sctx_ = 0;
 #endif
@@ -370,6 +382,10 @@ struct Tracer {
     tab_.sh = s.log2res;
     tab_.res = 1u << s.log2res;
     tab_.fres = (float)(1u << s.log2res);
+#if RM_UDIV
+    inv_sf_full_ = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / ((float)s.o->maxVoxelIter * 0.5f))));
+    inv_sf_half_ = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / ((float)(s.o->maxVoxelIter / 2) * 0.5f))));
+#endif
     if (LAYOUT == 2) {
       const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
       tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
@@ -575,7 +591,17 @@ struct Tracer {
       const v3 ivs = ld3(o.invVoxelScale);
       v3 delta;
       if (ACCEL) {
+#if RM_UDIV  // the divisor is uniform (steps is one of two values of the record): its reciprocal once per kernel
+        rmd::Divisor by_sf;
+        by_sf.b = sf;
+        by_sf.y = steps == o.maxVoxelIter ? inv_sf_full_ : (steps == o.maxVoxelIter / 2 ? inv_sf_half_ : 1.0f / sf);
+        {
+          const float ab = __builtin_fabsf(sf);
+          by_sf.ok = (ab >= 0x1p-30f) & (ab <= 0x1p30f) & ((__float_as_uint(sf) & 0x7fffffu) != 0x7fffffu);
+        }
+#else
         const rmd::Divisor by_sf = rmd::make_divisor(sf);
+#endif
         delta = V(rmd::div_by(dir.x, by_sf), rmd::div_by(dir.y, by_sf), rmd::div_by(dir.z, by_sf)) * ivs;
       } else {
         delta = V(dir.x / sf, dir.y / sf, dir.z / sf) * ivs;
@@ -618,9 +644,15 @@ struct Tracer {
         } while (r == 0);
         stat_wave(ST_HIT_W, sctx_); stat_count(ST_HIT_L, sctx_, r == 1);
 #else
+#if RM_PRIO
+        __builtin_amdgcn_s_setprio(RM_PRIO);  // a wave in its chain of dependent table fetches goes first
+#endif
         do {
           r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off);
         } while (r == 0);
+#if RM_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
         if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
@@ -1098,9 +1130,38 @@ struct Tracer {
         float sd, scode;
         v3 nn;
         const v3 rpos = mads(n, d, opos);
+#if RM_AO_FAR
+        // A probe whose start is farther from the box of all possible hit points than its result can depend
+        // on returns the ground term without a slab test or a walk: a hit at distance D from rpos only matters
+        // when D - voxelSize < min(d, g) (ao_walk_limit), every hit point p*voxelBounds2 - voxelBounds with p in
+        // [0,1)^3 lies in the box spanned by -voxelBounds and voxelBounds2 - voxelBounds, and the largest
+        // per-axis gap to that box bounds the distance from below.  (Most AO probes of ground hits beside the
+        // volume: ~half of all probes of the bench scene.)
+        const float g_ao = rpos.y + o.groundY;
+        bool far = false;
+        if ((o.aoAmp >= 0.0f) & (d > 0.0f)) {  // (uniform) the conditions of ao_walk_limit's argument
+          const float ax0 = -o.voxelBounds[0], ax1 = o.voxelBounds2[0] - o.voxelBounds[0];
+          const float ay0 = -o.voxelBounds[1], ay1 = o.voxelBounds2[1] - o.voxelBounds[1];
+          const float az0 = -o.voxelBounds[2], az1 = o.voxelBounds2[2] - o.voxelBounds[2];
+          const float gx = fmaxf(fminf(ax0, ax1) - rpos.x, rpos.x - fmaxf(ax0, ax1));
+          const float gy = fmaxf(fminf(ay0, ay1) - rpos.y, rpos.y - fmaxf(ay0, ay1));
+          const float gz = fmaxf(fminf(az0, az1) - rpos.z, rpos.z - fmaxf(az0, az1));
+          const float gap = fmaxf(fmaxf(gx, gy), gz);
+          const float need_d = (fmaxf(fminf(d, g_ao), 0.0f) + __builtin_fabsf(o.voxelSize)) * 1.001f + 1e-4f;
+          far = gap > need_d;  // (NaN anywhere: false)
+        }
+        if (far) {
+          sd = g_ao < 1e5f ? g_ao : 1e5f;  // renderer.cl:211-212: what the estimate returns when nothing is closer
+        } else {
+          const int ao_limit = ao_walk_limit(d, g_ao, o.maxVoxelIter / 2);
+          scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
+        }
+        lds_res(probe, owner) = sd;
+#else
         const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
         scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
         lds_res(probe, owner) = sd;
+#endif
       }
     }
     wave_sync();

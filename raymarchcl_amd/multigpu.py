@@ -97,6 +97,10 @@ class _Slot:
         self.stream = stream
         self.d_tiles = (torch.zeros(tpp * TILE_PIXELS * 4, dtype=torch.float32, device=dev)
                         if world > 1 else None)
+        # frames that want the ARGB image only are exchanged as tonemapped words (4 B per pixel, not 16)
+        self.d_argb_tiles = (torch.zeros(tpp * TILE_PIXELS, dtype=torch.int32, device=dev)
+                             if world > 1 and want_argb and not want_pixels else None)
+        self.events = None  # render(timed=True): share start / share end / gather end / resolve end
         self.d_pixels = torch.empty(4 * n, dtype=torch.float32, device=dev) if (root and want_pixels) else None
         self.d_argb = torch.empty(n, dtype=torch.int32, device=dev) if (root and want_argb) else None
         self.ctx = _native.Context(dev.index or 0)
@@ -166,12 +170,21 @@ class FrameRenderer:
         self.d_pixels, self.d_argb = self.slots[0].d_pixels, self.slots[0].d_argb
         torch.cuda.synchronize(dev)
 
-    def render(self):
+    def render(self, timed=False):
         """One frame.  Asynchronous; returns the (pixels, argb) tensors of the slot it
-        used, valid on the root once that slot's stream (or the device) is synchronised."""
+        used, valid on the root once that slot's stream (or the device) is synchronised.
+        timed: record events around this rank's share, the gather and the resolve on the slot's
+        stream (``last_breakdown()`` reads them)."""
         torch = self.torch
         slot = self.slots[self.frame % len(self.slots)]
         self.frame += 1
+        self._timed_slot = slot if timed else None
+        if timed:
+            if slot.events is None:
+                slot.events = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            mark = lambda i: slot.events[i].record(slot.stream)  # noqa: E731
+        else:
+            mark = lambda i: None  # noqa: E731
         with torch.cuda.stream(slot.stream):
             if self.world == 1:  # the whole frame incl. tonemap is one kernel launch
                 slot.ctx.frame_device_full(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
@@ -179,18 +192,42 @@ class FrameRenderer:
                                            slot.d_pixels.data_ptr() if slot.d_pixels is not None else None,
                                            slot.d_argb.data_ptr() if slot.d_argb is not None else None)
                 return slot.d_pixels, slot.d_argb
+            mark(0)
+            if slot.d_argb_tiles is not None:  # ARGB only: every rank tonemaps its tiles, words are exchanged
+                slot.ctx.frame_device_argb(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
+                                           self.width, slot.d_tiles.data_ptr(), slot.d_argb_tiles.data_ptr(),
+                                           self.rank, self.world)
+                mark(1)
+                allt = self._gather(slot, words=True)
+                mark(2)
+                if self.rank == 0:
+                    slot.ctx.resolve_device_argb(allt.data_ptr(), self.world, self.n, self.width, slot.d_argb.data_ptr())
+                mark(3)
+                return slot.d_pixels, slot.d_argb
             slot.ctx.frame_device(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
                                   self.width, slot.d_tiles.data_ptr(), self.rank, self.world)
+            mark(1)
             allt = self._gather(slot)
+            mark(2)
             if self.rank == 0:
                 slot.ctx.resolve_device(allt.data_ptr(), self.world, self.d_opts.data_ptr(), self.n,
                                         self.width,
                                         slot.d_pixels.data_ptr() if slot.d_pixels is not None else None,
                                         slot.d_argb.data_ptr() if slot.d_argb is not None else None)
+            mark(3)
         return slot.d_pixels, slot.d_argb
 
-    def _gather(self, slot):
-        """The frame's one collective.  With RCCL the root's receive buffer and its per-rank
+    def last_breakdown(self):
+        """(share_ms, gather_ms, resolve_ms) of the last ``render(timed=True)`` on this rank: device time of
+        the rank's own kernels, of the collective as this rank's stream sees it (for the root: until the
+        last rank's tiles have arrived, i.e. including the wait for the slowest rank), of the root's resolve."""
+        slot = self._timed_slot
+        slot.events[3].synchronize()
+        e = slot.events
+        return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])
+
+    def _gather(self, slot, words=False):
+        """The frame's one collective (of the float4 accumulators, or -- words -- of the ARGB words).  With RCCL the root's receive buffer and its per-rank
         views are made once per slot (a frame of an 8-GPU share lasts well under a millisecond:
         per-frame allocations and list building would show); other backends go through
         gather_tiles()."""
@@ -198,16 +235,16 @@ class FrameRenderer:
             return slot.d_tiles
         import torch.distributed as dist
 
+        mine = slot.d_argb_tiles if words else slot.d_tiles
         if dist.get_backend(self.group) != "nccl":
-            return gather_tiles(slot.d_tiles, self.rank, self.world, group=self.group)
+            return gather_tiles(mine, self.rank, self.world, group=self.group)
         if self.rank == 0:
             if getattr(slot, "d_all", None) is None:
-                slot.d_all = self.torch.empty(self.world * slot.d_tiles.numel(), dtype=slot.d_tiles.dtype,
-                                              device=self.device)
+                slot.d_all = self.torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=self.device)
                 slot.chunks = list(slot.d_all.view(self.world, -1).unbind(0))
-            dist.gather(slot.d_tiles, gather_list=slot.chunks, dst=0, group=self.group)
+            dist.gather(mine, gather_list=slot.chunks, dst=0, group=self.group)
             return slot.d_all
-        dist.gather(slot.d_tiles, gather_list=None, dst=0, group=self.group)
+        dist.gather(mine, gather_list=None, dst=0, group=self.group)
         return None
 
     def close(self):

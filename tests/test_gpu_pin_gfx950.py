@@ -102,3 +102,34 @@ def test_metric_against_every_reference_build(rendered, refs):
         # against ocml's; the reference builds agree among themselves on 97.3-99.2 %
         assert frac >= 0.95, (b, frac, among)
         assert frac_stable >= 0.96, (b, frac_stable)
+
+
+def test_config2_full_size_against_the_references_own_build(refs, native):
+    """BASELINE's headline configuration (256^3 gyroid, 1280x720, 16 passes + DOF) at FULL size, the
+    product in its default (device) contract against `fast` = the reference built with ITS OWN options
+    (-cl-fast-relaxed-math -cl-mad-enable, core.clj:128) -- north star's "pixels within 1e-4 of the
+    OpenCL reference".  16 blended passes make a pixel differ as soon as ONE hit/miss decision of one
+    pass flips under a re-rounding, so two builds of the reference itself agree on ~60 % of the pixels
+    only (profiles/r03_pin_gfx950.txt); asserted here: the product is at least as close to `fast` as
+    the closest other build of the reference is, and within 1e-4 on EVERY pixel on which the three
+    reference builds agree among themselves."""
+    import bench
+
+    wl = bench.WORKLOADS["c2"]
+    vox, vres, opts, mc = bench.build_inputs(wl)
+    n = wl["w"] * wl["h"]
+    px = {b: refs.gfx950_render_frame(vox, opts, mc, n, build=b, tonemap=False)[0] for b in refs.GFX950_BUILDS}
+    with native.Context(0) as ctx:  # library default: RM_CONTRACT_GFX950
+        ctx.set_volume(vox, vres)
+        got, _ = ctx.render_frame(opts, mc, n, want_argb=False)
+    stable = (rel(px["fast"], px["strict"]) <= 1e-4) & (rel(px["fast"], px["default"]) <= 1e-4) & \
+             (rel(px["default"], px["strict"]) <= 1e-4)
+    among_fast = max((rel(px["fast"], px[b]) <= 1e-4).mean() for b in ("default", "strict"))
+    r = rel(got, px["fast"])
+    frac, frac_stable = float((r <= 1e-4).mean()), float((r[stable] <= 1e-4).mean())
+    print(f"c2 full size: product vs `fast` {100 * frac:.3f} % of {n} pixels within 1e-4 (closest other reference build: "
+          f"{100 * among_fast:.3f} %); stable pixels {100 * stable.mean():.3f} %, product within 1e-4 on {100 * frac_stable:.4f} % of them")
+    assert np.array_equal(got.view(np.uint32), px["strict"].view(np.uint32))  # (and bit-exact against the strict build)
+    assert frac >= min((rel(px["fast"], px[b]) <= 1e-4).mean() for b in ("default", "strict")) - 1e-9
+    assert frac_stable == 1.0
+    assert 0.3 < stable.mean() < 1.0  # the metric is about a real, chaotic frame
