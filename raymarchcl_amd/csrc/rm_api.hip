@@ -90,7 +90,7 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::shared_ptr<Volume> vol;
-  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, rec_buf;
+  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
@@ -101,7 +101,6 @@ struct rm_ctx {
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
-  bool split_frame = false;  // RAYMARCH_SPLIT=1: a pass group as two launches (march kernel, light kernel) with hit records in HBM
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
   int contract = RM_CONTRACT_GFX950;  // rm_set_contract: RM_CONTRACT_GFX950 (default) / RM_CONTRACT_CPU_DEVICE
   // records validated by rm_check_device_opts
@@ -331,14 +330,6 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
     f.arith = (c->contract == RM_CONTRACT_GFX950 && !sdf_frame) ? 2 : (c->seed_cast ? 1 : 0);
-    // two launches per pass group (marches -> hit records in HBM -> lighting): power-of-two cubic grids,
-    // records whose reflectIter leaves the record count small
-    if (c->split_frame && !sdf_frame && f.accel.log2res && !f.accel.bricked && f.arith != 1 &&
-        host_recs[i0].reflectIter >= 0 && host_recs[i0].reflectIter <= 3) {
-      f.rec_hits = 1 + host_recs[i0].reflectIter;
-      HIP_TRY(c->rec_buf.reserve(rmk::frame_record_bytes(f)));
-      f.rec = static_cast<float*>(c->rec_buf.p);
-    }
     HIP_TRY(rmk::launch_render_frame(c->stream, f));
     launches++;
     i0 = i1;
@@ -432,8 +423,6 @@ static int create_one(int device_id, rm_ctx** out) {
   if (pw && atoi(pw) >= 0 && atoi(pw) <= 100) c->pack_waste = atoi(pw);
   const char* p2 = getenv("RAYMARCH_POW2");
   if (p2) c->pow2_tables = p2[0] != '0';
-  const char* sp = getenv("RAYMARCH_SPLIT");
-  if (sp) c->split_frame = sp[0] == '1';
   *out = c;
   return RM_OK;
 }
@@ -492,7 +481,7 @@ void rm_destroy(rm_ctx* c) {
   for (const void* h : c->host_bufs) (void)hipHostUnregister(const_cast<void*>(h));
   c->host_bufs.clear();
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
-                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->rec_buf, &c->atile_buf};
+                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->atile_buf};
   for (DevBuf* b : bufs) b->release();
   c->vol.reset();
   if (c->ev0) (void)hipEventDestroy(c->ev0);

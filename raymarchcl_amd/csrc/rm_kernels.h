@@ -47,14 +47,9 @@ struct FrameLaunch {
   // arithmetic contract (rm_math.hpp): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
   // the seed casts (rm_set_seed_cast), 2 = ROCm's OpenCL library on this GPU (rm_set_contract)
   int arith = 0;
-  // not null: the frame as TWO launches (march kernel -> hit records here -> light kernel); used when the
-  // tables are in layout 2 (cubic power-of-two grid).  rec_hits records of 8 floats per sample (1 + reflectIter).
-  float* rec = nullptr;
-  int rec_hits = 0;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
-// bytes of hit records launch_render_frame needs for this launch when the frame goes out as two launches
-size_t frame_record_bytes(const FrameLaunch& f);
+
 int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,

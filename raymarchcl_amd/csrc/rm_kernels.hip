@@ -127,8 +127,6 @@ struct FrameArgs {
   unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int row_major;                       // acc is indexed by work-item id instead of slot*64 + pixel
-  float* __restrict__ rec;             // two-launch frames: hit records [block][hit][8][64] floats (rm_shade.hpp trace_chain)
-  int rec_hits;                        // records per sample = 1 + reflectIter of the launch's records
 };
 
 template <class M>
@@ -148,9 +146,7 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 // across the body of another, and the kernel has no loop over groups of passes.
 // ARITH: 0 = OpenCL CPU device arithmetic and casts, 1 = the same with the GPU lowering of the seed
 // casts, 2 = ROCm's OpenCL library on this GPU (rm_math.hpp)
-// MODE 0: the whole frame body; 1: the marches only, hit records to a.rec (march kernel); 2: lighting, blend and
-// tonemap from the records of a MODE 1 launch with the same grid (light kernel)
-template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH, int MODE = 0>
+template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
   using M = typename std::conditional<ARITH == 2, rmk::MathOcl, rmk::MathX86<(ARITH == 1 ? 1 : 0)>>::type;
   using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
@@ -188,9 +184,8 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   const int pl = lane & (pp - 1);  // this lane's pass within a group
   const bool first = pl == 0;      // the lane that keeps its pixel's accumulator
   const long long at = a.row_major ? (long long)id : slot * 64 + pix;
-  float* const rec_lane = MODE ? a.rec + ((size_t)hw_block * (size_t)a.rec_hits * Tr::kRecFloats) * 64 + lane : nullptr;
   float px = 0.f, py = 0.f, pz = 0.f;
-  if (MODE != 1 && a.accumulate && first) {
+  if (a.accumulate && first) {
     const float4 p = a.acc[at];
     px = p.x; py = p.y; pz = p.z;
   }
@@ -203,12 +198,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
-    if (MODE == 1) {
-      tr.trace_chain(id, live, rec_lane);
-      return;
-    }
-    if (MODE == 2) col = tr.shade_from_records(id, wave_lds, live, rec_lane);
-    else if (ACCEL) col = tr.shade_wave(id, wave_lds, live);
+    if (ACCEL) col = tr.shade_wave(id, wave_lds, live);
     else if (live) col = tr.shade(id);
     // mix(p, col, frameBlend) in pass order: renderer.cl:492
     if (pp > 1) {
@@ -244,18 +234,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
   __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
   frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
-}
-
-// The frame as two launches over the same grid (rm_shade.hpp): accelerated walks, table LAYOUT 2, device
-// arithmetic contract or CPU-device contract.
-template <int MINW, int LAYOUT, int ARITH>
-__global__ __launch_bounds__(64, MINW) void march_frame_kernel(const FrameArgs a) {
-  frame_block<true, false, LAYOUT, ARITH, 1>(a, blockIdx.x, nullptr);
-}
-template <int MINW, int LAYOUT, int ARITH>
-__global__ __launch_bounds__(64, MINW) void light_frame_kernel(const FrameArgs a) {
-  __shared__ float wave_lds[rmk::Tracer<false, true, false>::kWaveLdsFloats];
-  frame_block<true, false, LAYOUT, ARITH, 2>(a, blockIdx.x, wave_lds);
 }
 
 template <bool DEVICE>
@@ -447,10 +425,6 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
   return blocks;
 }
 
-size_t frame_record_bytes(const FrameLaunch& f) {
-  return (size_t)frame_grid(f, nullptr, nullptr) * (size_t)(f.rec_hits > 0 ? f.rec_hits : 0) * 8 * 64 * sizeof(float);
-}
-
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   const TileGeom g = tile_geom(f.resx, f.n);
   const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
@@ -487,24 +461,6 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
     else RM_FRAME(A, W, S, B, 0);                   \
   } while (0)
   a.log2res = f.accel.log2res;
-  a.rec = f.rec;
-  a.rec_hits = f.rec_hits;
-#ifndef RM_MARCH_MINW
-#define RM_MARCH_MINW 7
-#endif
-#ifndef RM_LIGHT_MINW
-#define RM_LIGHT_MINW 7
-#endif
-  if (f.rec && !f.sdf && f.accel.dist && f.accel.surf && f.accel.log2res && !f.accel.bricked && f.arith != 1) {
-    if (f.arith == 2) {
-      march_frame_kernel<RM_MARCH_MINW, 2, 2><<<grid, block, 0, st>>>(a);
-      light_frame_kernel<RM_LIGHT_MINW, 2, 2><<<grid, block, 0, st>>>(a);
-    } else {
-      march_frame_kernel<RM_MARCH_MINW, 2, 0><<<grid, block, 0, st>>>(a);
-      light_frame_kernel<RM_LIGHT_MINW, 2, 0><<<grid, block, 0, st>>>(a);
-    }
-    return hipGetLastError();
-  }
   if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
     if (f.arith == 1) RM_FRAME(false, 4, true, 0, 1); else RM_FRAME(false, 4, true, 0, 0);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
@@ -563,16 +519,3 @@ hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, 
 
 }  // namespace rmk
 
-#if RM_STATS
-// measurement build only (tools/wave_stats.py): read / reset the event counts of rm_shade.hpp
-extern "C" int rm_debug_stats(unsigned long long* out, int n, int reset) {
-  if (n > 256) n = 256;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rmk::rm_stats_dev), sizeof(unsigned long long) * n) != hipSuccess) return -2;
-  if (reset) {
-    static unsigned long long zeros[256];
-    if (hipMemcpyToSymbol(HIP_SYMBOL(rmk::rm_stats_dev), zeros, sizeof(zeros)) != hipSuccess) return -3;
-  }
-  return 0;
-}
-#endif

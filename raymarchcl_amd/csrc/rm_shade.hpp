@@ -22,57 +22,6 @@ struct Counters {
 
 struct Material { v3 albedo; float r0, smoothness; };
 
-// -DRM_STATS=1: wave-level / lane-level event counts of the accelerated frame kernel (a measurement
-// build, tools/wave_stats.py; never the product).  Index = event * 5 + context
-// (0 primary march, 1 reflection march, 2 AO probe, 3 shadow march, 4 repeat of a cut turn).
-#ifndef RM_STATS
-#define RM_STATS 0
-#endif
-#ifndef RM_JCAP
-#define RM_JCAP 0
-#endif
-#ifndef RM_X_FMAJUMP
-#define RM_X_FMAJUMP 0
-#endif
-#ifndef RM_ADDS
-#define RM_ADDS 0
-#endif
-#ifndef RM_BOXDIV
-#define RM_BOXDIV 0
-#endif
-#ifndef RM_AO_FAR
-#define RM_AO_FAR 0
-#endif
-#ifndef RM_UDIV
-#define RM_UDIV 0
-#endif
-#ifndef RM_PRIO
-#define RM_PRIO 0
-#endif
-#if RM_STATS
-__device__ unsigned long long rm_stats_dev[256];
-enum { ST_EST_W, ST_EST_L, ST_BOX_L, ST_WALK_W, ST_WALK_L, ST_TRIP_W, ST_TRIP_L, ST_GO_L, ST_J_L, ST_JMAX_W,
-       ST_ADDIT_W, ST_HIT_W, ST_HIT_L, ST_ROUND_W, ST_ROUND_L, ST_FILT_W, ST_FILT_L, ST_MARCH_W, ST_MARCH_L,
-       ST_PHASE_W, ST_TASK_L, ST_PROUND_W, ST_J1_L, ST_J3_L, ST_JMAX8_W, ST_JMAX16_W };
-RM_DEV void stat_add(int ev, int ctx, unsigned long long v) {  // by the first active lane
-  const unsigned long long act = __ballot(1);
-  if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&rm_stats_dev[ev * 5 + ctx], v);
-}
-RM_DEV void stat_wave(int ev, int ctx) { stat_add(ev, ctx, 1ull); }
-RM_DEV void stat_lanes(int ev, int ctx) { stat_add(ev, ctx, (unsigned long long)__popcll(__ballot(1))); }
-RM_DEV void stat_count(int ev, int ctx, bool c) { stat_add(ev, ctx, (unsigned long long)__popcll(__ballot(c))); }
-RM_DEV int stat_max(int v) {  // max over the active lanes, 0 <= v < 4096
-  int m = 0;
-  for (int b = 11; b >= 0; b--) if (__ballot(v >= (m | (1 << b)))) m |= 1 << b;
-  return m;
-}
-RM_DEV void stat_sum(int ev, int ctx, int v) {  // sum over the active lanes, 0 <= v < 4096
-  unsigned long long t = 0;
-  for (int b = 0; b < 12; b++) t += (unsigned long long)__popcll(__ballot((v >> b) & 1)) << b;
-  stat_add(ev, ctx, t);
-}
-#endif
-
 // Everything a sample needs that is uniform across the launch.
 struct Scene {
   const uint8_t* __restrict__ vox;
@@ -106,18 +55,10 @@ RM_DEV Material material_of(const RmOpts& o, int id, bool* oob = nullptr) {
 // slab test: renderer.cl:153-161
 template <class M>
 RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
-#if RM_BOXDIV  // the two quotients of an axis share their divisor (rmd::div_by == IEEE division, bit for bit)
-  const rmd::Divisor bx = rmd::make_divisor(d.x), by = rmd::make_divisor(d.y), bz = rmd::make_divisor(d.z);
-  const float lox = rmd::div_by(o.voxelBoundsMin[0] - p.x, bx), loy = rmd::div_by(o.voxelBoundsMin[1] - p.y, by),
-              loz = rmd::div_by(o.voxelBoundsMin[2] - p.z, bz);
-  const float hix = rmd::div_by(o.voxelBoundsMax[0] - p.x, bx), hiy = rmd::div_by(o.voxelBoundsMax[1] - p.y, by),
-              hiz = rmd::div_by(o.voxelBoundsMax[2] - p.z, bz);
-#else
   const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
               loz = (o.voxelBoundsMin[2] - p.z) / d.z;
   const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
               hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
-#endif
   const float nx = M::fmin(hix, lox), ny = M::fmin(hiy, loy), nz = M::fmin(hiz, loz);
   const float a = M::fmax(M::fmax(nx, 0.0f), M::fmax(ny, nz));
   const float fx = M::fmax(hix, lox), fy = M::fmax(hiy, loy), fz = M::fmax(hiz, loz);
@@ -206,11 +147,7 @@ struct WalkTab {
 };
 template <class M, int LAYOUT>
 RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 delta, float inv_s, float c0,
-                     int* cell_out, unsigned long long table_off
-#if RM_STATS
-                     , int sctx
-#endif
-                     ) {
+                     int* cell_out, unsigned long long table_off) {
   int d, j;
   unsigned cell;
   if (LAYOUT == 2) {
@@ -224,25 +161,10 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
     cell = ((((unsigned)qz << tab.sh) | (unsigned)qy) << tab.sh) | (unsigned)qx;
     d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell + (unsigned)table_off, 0, 0);
     j = max((int)__builtin_fmaf((float)d, inv_s, c0), 1);
-#if RM_JCAP
-    j = min(j, RM_JCAP);  // (exact: a shorter skip is always valid)
-#endif
     *cell_out = (int)cell;
     // one decision per sample: hit / go on / end
     const bool hit = ok & (d == 0);
     const bool go = ok & (d != 0) & (j < steps);
-#if RM_STATS
-    stat_wave(ST_TRIP_W, sctx); stat_lanes(ST_TRIP_L, sctx); stat_count(ST_GO_L, sctx, go);
-    {
-      const int jj = go ? j : 0;
-      stat_sum(ST_J_L, sctx, jj);
-      const int jm = stat_max(jj);
-      stat_add(ST_JMAX_W, sctx, (unsigned long long)jm);
-      stat_add(ST_ADDIT_W, sctx, (unsigned long long)(jm > 1 ? (jm - 1) / 4 : 0));
-      stat_count(ST_J1_L, sctx, go & (j == 1)); stat_count(ST_J3_L, sctx, go & (j <= 3));
-      stat_add(ST_JMAX8_W, sctx, jm > 8 ? 1ull : 0ull); stat_add(ST_JMAX16_W, sctx, jm > 16 ? 1ull : 0ull);
-    }
-#endif
     if (!go) return hit ? 1 : 2;
   } else {
     const int qx = M::cell(p.x * (float)o.voxelRes[0]);
@@ -278,53 +200,8 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
   // adds per skipped sample are cheaper than its bookkeeping and failure path.)
   // (on average 5 samples are advanced per fetch: the adds are unrolled by four so that
   //  the loop bookkeeping does not cost more than the adds themselves)
-#if RM_X_FMAJUMP  // INEXACT timing probe: what a closed-form jump could be worth at most
-  p = V(__builtin_fmaf((float)j, delta.x, p.x), __builtin_fmaf((float)j, delta.y, p.y), __builtin_fmaf((float)j, delta.z, p.z));
-  steps -= j;
-  return 0;
-#endif
   p = p + delta;
   int k = j - 1;
-#if RM_ADDS == 1  // pairs + one
-  while (k >= 2) {
-    p = p + delta;
-    p = p + delta;
-    k -= 2;
-  }
-  if (k & 1) p = p + delta;
-#elif RM_ADDS == 2  // fours, then the rest as real branches (an empty asm keeps the compiler from turning them into selects)
-  while (k >= 4) {
-    p = p + delta;
-    p = p + delta;
-    p = p + delta;
-    p = p + delta;
-    k -= 4;
-  }
-  if (k & 2) {
-    asm volatile("");
-    p = p + delta;
-    p = p + delta;
-  }
-  if (k & 1) {
-    asm volatile("");
-    p = p + delta;
-  }
-#elif RM_ADDS == 3  // one sample per turn
-  while (k > 0) {
-    p = p + delta;
-    k -= 1;
-  }
-#elif RM_ADDS == 4  // pairs, the odd one as a real branch
-  while (k >= 2) {
-    p = p + delta;
-    p = p + delta;
-    k -= 2;
-  }
-  if (k & 1) {
-    asm volatile("");
-    p = p + delta;
-  }
-#else
   while (k >= 4) {
     p = p + delta;
     p = p + delta;
@@ -337,7 +214,6 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
     p = p + delta;
   }
   if (k & 1) p = p + delta;
-#endif
   steps -= j;
   return 0;
 }
@@ -371,21 +247,11 @@ struct Tracer {
   // lanes of a wavefront hand AO probes and shadow rays to each other (shade_wave()).
   float* lds_ = nullptr;
   WalkTab tab_;  // the skip tables as walk_step reads them (uniform)
-#if RM_UDIV
-  float inv_sf_full_, inv_sf_half_;  // 1 / (steps * 0.5) for steps = maxVoxelIter and maxVoxelIter / 2 (uniform)
-#endif
-#if RM_STATS
-  int sctx_ = 0;
-#endif
   RM_DEV explicit Tracer(const Scene& s) : sc(s), mc_(s.mc), time_(s.o->time), cnt{} {
     tab_.dist8 = s.dist;
     tab_.sh = s.log2res;
     tab_.res = 1u << s.log2res;
     tab_.fres = (float)(1u << s.log2res);
-#if RM_UDIV
-    inv_sf_full_ = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / ((float)s.o->maxVoxelIter * 0.5f))));
-    inv_sf_half_ = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / ((float)(s.o->maxVoxelIter / 2) * 0.5f))));
-#endif
     if (LAYOUT == 2) {
       const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
       tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
@@ -582,26 +448,13 @@ struct Tracer {
                      (rpos.y - o.voxelBoundsMin[1] > m) & (o.voxelBoundsMax[1] - rpos.y > m) &
                      (rpos.z - o.voxelBoundsMin[2] > m) & (o.voxelBoundsMax[2] - rpos.z > m);
     }
-#if RM_STATS
-    if (ACCEL) { stat_wave(ST_EST_W, sctx_); stat_lanes(ST_EST_L, sctx_); stat_count(ST_BOX_L, sctx_, !known_inside); }
-#endif
     const float t_in = known_inside ? 0.0f : box_entry(rpos, dir);
     if (t_in >= 0.0f && t_in < rd) {
       const float sf = (float)steps * 0.5f;
       const v3 ivs = ld3(o.invVoxelScale);
       v3 delta;
       if (ACCEL) {
-#if RM_UDIV  // the divisor is uniform (steps is one of two values of the record): its reciprocal once per kernel
-        rmd::Divisor by_sf;
-        by_sf.b = sf;
-        by_sf.y = steps == o.maxVoxelIter ? inv_sf_full_ : (steps == o.maxVoxelIter / 2 ? inv_sf_half_ : 1.0f / sf);
-        {
-          const float ab = __builtin_fabsf(sf);
-          by_sf.ok = (ab >= 0x1p-30f) & (ab <= 0x1p30f) & ((__float_as_uint(sf) & 0x7fffffu) != 0x7fffffu);
-        }
-#else
         const rmd::Divisor by_sf = rmd::make_divisor(sf);
-#endif
         delta = V(rmd::div_by(dir.x, by_sf), rmd::div_by(dir.y, by_sf), rmd::div_by(dir.z, by_sf)) * ivs;
       } else {
         delta = V(dir.x / sf, dir.y / sf, dir.z / sf) * ivs;
@@ -637,23 +490,9 @@ struct Tracer {
         // others and all hits are then evaluated together (inside the loop the compiler
         // runs the hit code once per trip in which any lane finishes)
         int cell = 0, r;
-#if RM_STATS
-        stat_wave(ST_WALK_W, sctx_); stat_lanes(ST_WALK_L, sctx_);
-        do {
-          r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off, sctx_);
-        } while (r == 0);
-        stat_wave(ST_HIT_W, sctx_); stat_count(ST_HIT_L, sctx_, r == 1);
-#else
-#if RM_PRIO
-        __builtin_amdgcn_s_setprio(RM_PRIO);  // a wave in its chain of dependent table fetches goes first
-#endif
         do {
           r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off);
         } while (r == 0);
-#if RM_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#endif
         if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
@@ -790,22 +629,13 @@ struct Tracer {
     const float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
-#if RM_STATS
-    if (ACCEL) { stat_wave(ST_MARCH_W, sctx_); stat_lanes(ST_MARCH_L, sctx_); }
-#endif
     for (;;) {
       float g = 0.0f;
       why = 2;
-#if RM_STATS
-      if (ACCEL) { stat_wave(ST_ROUND_W, sctx_); stat_lanes(ST_ROUND_L, sctx_); }
-#endif
       if (maxSteps > 0) {
         // one exit: a turn either continues (filtered, not converged, turns left) or not
         bool nw, go;
         do {
-#if RM_STATS
-          if (ACCEL) { stat_wave(ST_FILT_W, sctx_); stat_lanes(ST_FILT_L, sctx_); }
-#endif
           maxSteps--;
           last_t = dist;
           const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
@@ -841,14 +671,7 @@ struct Tracer {
       r.pos = muladd(rdir, last_t, ro);
       if (ACCEL && !distance_only && last_kind == 1 && cut_last) {
         float sd2, sc2;
-#if RM_STATS
-        const int keep_ctx = sctx_;
-        sctx_ = 4;
-#endif
         scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
-#if RM_STATS
-        sctx_ = keep_ctx;
-#endif
       }
       if (last_kind == 0) {  // renderer.cl:211-212 for the ground / sky term
         const float h = (rdir.y * last_t + ro.y) + o.groundY;
@@ -1101,15 +924,8 @@ struct Tracer {
     }
     wave_sync();
     const int tasks = np * dl.owners;
-#if RM_STATS
-    sctx_ = 2;
-    stat_wave(ST_PHASE_W, 2); stat_add(ST_TASK_L, 2, (unsigned long long)tasks);
-#endif
     for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
       const int t = base + dl.my_slot;
-#if RM_STATS
-      stat_wave(ST_PROUND_W, 2);
-#endif
       if (t < tasks) {
         int probe, rank;
         divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
@@ -1130,38 +946,9 @@ struct Tracer {
         float sd, scode;
         v3 nn;
         const v3 rpos = mads(n, d, opos);
-#if RM_AO_FAR
-        // A probe whose start is farther from the box of all possible hit points than its result can depend
-        // on returns the ground term without a slab test or a walk: a hit at distance D from rpos only matters
-        // when D - voxelSize < min(d, g) (ao_walk_limit), every hit point p*voxelBounds2 - voxelBounds with p in
-        // [0,1)^3 lies in the box spanned by -voxelBounds and voxelBounds2 - voxelBounds, and the largest
-        // per-axis gap to that box bounds the distance from below.  (Most AO probes of ground hits beside the
-        // volume: ~half of all probes of the bench scene.)
-        const float g_ao = rpos.y + o.groundY;
-        bool far = false;
-        if ((o.aoAmp >= 0.0f) & (d > 0.0f)) {  // (uniform) the conditions of ao_walk_limit's argument
-          const float ax0 = -o.voxelBounds[0], ax1 = o.voxelBounds2[0] - o.voxelBounds[0];
-          const float ay0 = -o.voxelBounds[1], ay1 = o.voxelBounds2[1] - o.voxelBounds[1];
-          const float az0 = -o.voxelBounds[2], az1 = o.voxelBounds2[2] - o.voxelBounds[2];
-          const float gx = fmaxf(fminf(ax0, ax1) - rpos.x, rpos.x - fmaxf(ax0, ax1));
-          const float gy = fmaxf(fminf(ay0, ay1) - rpos.y, rpos.y - fmaxf(ay0, ay1));
-          const float gz = fmaxf(fminf(az0, az1) - rpos.z, rpos.z - fmaxf(az0, az1));
-          const float gap = fmaxf(fmaxf(gx, gy), gz);
-          const float need_d = (fmaxf(fminf(d, g_ao), 0.0f) + __builtin_fabsf(o.voxelSize)) * 1.001f + 1e-4f;
-          far = gap > need_d;  // (NaN anywhere: false)
-        }
-        if (far) {
-          sd = g_ao < 1e5f ? g_ao : 1e5f;  // renderer.cl:211-212: what the estimate returns when nothing is closer
-        } else {
-          const int ao_limit = ao_walk_limit(d, g_ao, o.maxVoxelIter / 2);
-          scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
-        }
-        lds_res(probe, owner) = sd;
-#else
         const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
         scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
         lds_res(probe, owner) = sd;
-#endif
       }
     }
     wave_sync();
@@ -1200,15 +987,8 @@ struct Tracer {
       tasks += __popcll(mk);
     }
     wave_sync();
-#if RM_STATS
-    sctx_ = 3;
-    stat_wave(ST_PHASE_W, 3); stat_add(ST_TASK_L, 3, (unsigned long long)tasks);
-#endif
     for (int base = 0; base < tasks; base += dl.helpers) {
       const int t = base + dl.my_slot;
-#if RM_STATS
-      stat_wave(ST_PROUND_W, 3);
-#endif
       if (t < tasks) {
         const int e = task_of[t];
         const int light = e >> 6, owner = e & 63;
@@ -1312,9 +1092,6 @@ struct Tracer {
   RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
     const RmOpts& o = *sc.o;
     Hit h{};
-#if RM_STATS
-    sctx_ = 0;
-#endif
     if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
     const bool hit = live && !(h.distance >= o.maxDist);
     v3 norm = V(0.f, 0.f, 0.f);
@@ -1336,9 +1113,6 @@ struct Tracer {
       for (int i = 0; i < o.reflectIter; i++) {  // uniform bound; lanes drop out through `alive`
         if (__ballot(alive) == 0) break;         // uniform
         v3 from = V(0.f, 0.f, 0.f);
-#if RM_STATS
-        sctx_ = 1;
-#endif
         if (alive) {
           dir = reflect(dir, rh.normal);
           from = muladd(dir, 0.0075f, rh.pos);
@@ -1358,113 +1132,6 @@ struct Tracer {
     const v3 lit = lighting_wave(hit, s, rdir, h.pos, h.objectID, norm, false, refl);
     const v3 col = hit ? lit : sky(rdir);
     return atmosphere(s, ro, rdir, h.distance, col);
-  }
-
-  // =====================================================================================
-  // The frame as TWO launches (rm_kernels.hip: march kernel, then light kernel).
-  //
-  // The chain of marches of a sample -- primary ray, then up to reflectIter mirror bounces -- never
-  // looks at a lighting result (renderer.cl:426-438: the next bounce starts from the hit's position
-  // and normal, the colours are only summed), so it can run first for every sample and leave one
-  // record per hit in HBM: position, normal (the perturbed one for the primary hit), distance, object
-  // code = 8 floats, the 64 lanes of a wavefront side by side.  The light kernel re-derives the sample
-  // (sample_init / camera_dir: the same code on the same inputs) and the bounce directions
-  // (reflect / muladd of recorded values: the same operations), runs the wave-shared phases of
-  // lighting_wave() for every recorded hit and blends.  Per sample the operations and their order are
-  // those of sample_colour_wave(), so the bits are too; what changes is that neither kernel carries
-  // the other's state through its loops.
-  // =====================================================================================
-  static constexpr int kRecFloats = 8;
-  RM_DEV static void rec_store(float* rec, int hit, v3 pos, v3 nrm, float distance, int objectID) {
-    float* r = rec + (size_t)hit * kRecFloats * 64;
-    r[0 * 64] = pos.x; r[1 * 64] = pos.y; r[2 * 64] = pos.z;
-    r[3 * 64] = nrm.x; r[4 * 64] = nrm.y; r[5 * 64] = nrm.z;
-    r[6 * 64] = distance;
-    r[7 * 64] = __int_as_float(objectID);
-  }
-  RM_DEV static void rec_load(const float* rec, int hit, v3& pos, v3& nrm, float& distance, int& objectID) {
-    const float* r = rec + (size_t)hit * kRecFloats * 64;
-    pos = V(r[0 * 64], r[1 * 64], r[2 * 64]);
-    nrm = V(r[3 * 64], r[4 * 64], r[5 * 64]);
-    distance = r[6 * 64];
-    objectID = __float_as_int(r[7 * 64]);
-  }
-  // march kernel: everything of sample_colour_wave() that is a march
-  RM_DEV void trace_chain(int id, bool live, float* rec) {
-    const RmOpts& o = *sc.o;
-    const Sample s = sample_init(id);
-    const v3 rdir = camera_dir(s);
-    Hit h{};
-    if (live) march(s.eye, rdir, h, o.maxDist, o.maxIter, true);
-    const bool hit = live && !(h.distance >= o.maxDist);
-    v3 norm = V(0.f, 0.f, 0.f);
-    float r0 = 0.0f;
-    if (hit) {
-      const Material m = material(h.objectID);
-      const float k = 1.0f / M::mad(m.smoothness, 200.0f, 5.0f);
-      norm = mads(s.mcNormal, k, h.normal);
-      r0 = m.r0;
-    }
-    rec_store(rec, 0, h.pos, norm, h.distance, h.objectID);
-    bool alive = hit && r0 > 0.0f && o.reflectIter > 0;
-    Hit rh{};
-    rh.pos = h.pos;
-    rh.normal = norm;
-    v3 dir = rdir;
-    for (int i = 0; i < o.reflectIter; i++) {
-      if (__ballot(alive) == 0) break;  // uniform
-      if (alive) {
-        dir = reflect(dir, rh.normal);
-        const v3 from = muladd(dir, 0.0075f, rh.pos);
-        march(from, dir, rh, o.maxDist, o.maxIter, false);
-        rec_store(rec, i + 1, rh.pos, rh.normal, rh.distance, rh.objectID);
-        if (rh.objectID < 0) alive = false;
-        else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
-      }
-    }
-  }
-  // light kernel: sample_colour_wave() with the marches read back
-  RM_DEV v3 shade_from_records(int id, float* lds, bool live, const float* rec) {
-    lds_ = lds;
-    const RmOpts& o = *sc.o;
-    const Sample s = sample_init(id);
-    const v3 rdir = camera_dir(s);
-    Hit h{};
-    v3 norm = V(0.f, 0.f, 0.f);
-    if (live) rec_load(rec, 0, h.pos, norm, h.distance, h.objectID);
-    const bool hit = live && !(h.distance >= o.maxDist);
-    float r0 = 0.0f;
-    if (hit) r0 = material(h.objectID).r0;
-    const bool bounces = hit && r0 > 0.0f && o.reflectIter > 0;
-    v3 refl = V(0.f, 0.f, 0.f);
-    if (__ballot(bounces) != 0) {  // uniform
-      Hit rh{};
-      rh.pos = h.pos;
-      rh.normal = norm;
-      v3 dir = rdir;
-      bool alive = bounces;
-      for (int i = 0; i < o.reflectIter; i++) {
-        if (__ballot(alive) == 0) break;  // uniform
-        v3 from = V(0.f, 0.f, 0.f);
-        if (alive) {
-          dir = reflect(dir, rh.normal);
-          from = muladd(dir, 0.0075f, rh.pos);
-          rec_load(rec, i + 1, rh.pos, rh.normal, rh.distance, rh.objectID);
-        }
-        const bool bhit = alive && rh.objectID >= 0;
-        const v3 lit = lighting_wave(bhit, s, dir, rh.pos, rh.objectID, rh.normal, true, V(0.f, 0.f, 0.f));
-        if (alive) {
-          const v3 col = bhit ? lit : sky(dir);
-          refl = refl + atmosphere(s, from, dir, rh.distance, col);
-          if (rh.objectID < 0) alive = false;
-          else if ((double)material(rh.objectID).r0 < 0.001) alive = false;
-        }
-      }
-    }
-    if (hit && !bounces) refl = sky(reflect(rdir, norm));
-    const v3 lit = lighting_wave(hit, s, rdir, h.pos, h.objectID, norm, false, refl);
-    const v3 col = hit ? lit : sky(rdir);
-    return atmosphere(s, s.eye, rdir, h.distance, col) * o.exposure;
   }
 
   // shade() through the wave-shared path; every lane of the wavefront that has a pixel

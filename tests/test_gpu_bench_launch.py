@@ -114,3 +114,38 @@ def test_host_and_device_frames_interleaved_on_a_multi_device_context(native, or
         ctx.synchronize()
         assert np.array_equal(px.cpu().numpy().view(np.uint32), want_px.view(np.uint32))
         assert np.array_equal(argb.cpu().numpy().view(np.uint32), want_argb)
+
+
+@pytest.mark.parametrize("ranks", [2, 5])
+def test_argb_only_device_resident_frames_inside_the_library(native, ranks):
+    """rm_frame_device_full(d_pixels = NULL) on a multi-device context: the devices exchange tonemapped
+    words instead of accumulators; same image as the float path, frame after frame; the per-device
+    breakdown is reported."""
+    import torch
+
+    sc = scenes.build("metal_3spp")
+    n, it = sc["n"], sc["iter"]
+    dev = torch.device("cuda", 0)
+    d_opts = torch.frombuffer(bytearray(sc["opts"]), dtype=torch.uint8).to(dev)
+    d_mc = torch.from_numpy(np.ascontiguousarray(sc["mc"], np.float32).reshape(-1)).to(dev)
+    px = torch.zeros(4 * n, dtype=torch.float32, device=dev)
+    argb_f = torch.zeros(n, dtype=torch.int32, device=dev)
+    argb_w = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    with native.Context([0] * ranks) as ctx:
+        ctx.set_volume(sc["vox"], sc["vres"])
+        ctx.check_device_opts(d_opts.data_ptr(), it, n, sc["w"])
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), it, n, sc["w"], px.data_ptr(), argb_f.data_ptr())
+        for a in argb_w:  # words-only frames back to back, then a float frame again
+            ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), it, n, sc["w"], None, a.data_ptr())
+        ctx.synchronize()
+        shares, frame_ms = ctx.last_frame_breakdown()
+        assert len(shares) == ranks and all(s > 0 for s in shares) and frame_ms >= max(shares) * 0.5
+        want = argb_f.cpu().numpy()
+        assert len(np.unique(want)) > 100
+        for a in argb_w:
+            assert np.array_equal(a.cpu().numpy(), want)
+        px2 = torch.zeros_like(px)
+        ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), it, n, sc["w"], px2.data_ptr(), None)
+        ctx.synchronize()
+        assert torch.equal(px, px2)

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir, frames_in_flight=1, backend="gloo"):
+def _worker(rank, world, port, tmpdir, frames_in_flight=1, backend="gloo", want_pixels=True):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -46,12 +46,13 @@ def _worker(rank, world, port, tmpdir, frames_in_flight=1, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = scenes.build("metal_3spp")
     fr = multigpu.FrameRenderer(sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"], sc["w"], rank=rank,
-                                world=world, device=dev, frames_in_flight=frames_in_flight)
+                                world=world, device=dev, frames_in_flight=frames_in_flight, want_pixels=want_pixels)
     for _ in range(2 * frames_in_flight + 1):  # every slot reused at least once
         d_px, d_argb = fr.render()
     torch.cuda.synchronize()
     if rank == 0:
-        np.save(os.path.join(tmpdir, "px.npy"), d_px.cpu().numpy())
+        if d_px is not None:
+            np.save(os.path.join(tmpdir, "px.npy"), d_px.cpu().numpy())
         np.save(os.path.join(tmpdir, "argb.npy"), d_argb.cpu().numpy().view(np.uint32))
     dist.barrier()
     fr.close()
@@ -86,4 +87,18 @@ def test_tile_partition_over_rccl(tmp_path, pin, frames_in_flight):
     sc = scenes.build("metal_3spp")
     want, want_argb = pin.frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], sc["n"])
     assert np.array_equal(np.load(tmp_path / "px.npy").view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "argb.npy"), want_argb)
+
+
+@pytest.mark.parametrize("world,frames_in_flight", [(2, 1), (3, 2)])
+def test_argb_only_frames_exchange_tonemapped_words(tmp_path, pin, world, frames_in_flight):
+    """want_pixels=False: every rank tonemaps its own tiles in the frame kernel, the ARGB words (4 B per
+    pixel) are gathered and un-permuted by the root (rm_frame_device_argb / rm_resolve_device_argb):
+    the image equals the reference build's TonemapImage output word for word."""
+    import scenes
+
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), frames_in_flight, "gloo", False), nprocs=world, join=True)
+    sc = scenes.build("metal_3spp")
+    _want, want_argb = pin.frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    assert not os.path.exists(tmp_path / "px.npy")
     assert np.array_equal(np.load(tmp_path / "argb.npy"), want_argb)

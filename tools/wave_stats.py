@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Wave-level / lane-level event counts of the frame kernel on the bench workload (GPU).
 
-    python tools/ab_build.py stats="-DRM_STATS=1"
+    patch -p1 < tools/wave_stats.patch                  # the instrumentation is not in the product sources
+    python tools/ab_build.py stats="-DRM_STATS=1"; git checkout raymarchcl_amd/csrc
     RAYMARCH_LIB=libraymarch_hip_ab_stats.so python tools/wave_stats.py [--workload c2]
 
 Renders ONE frame with the -DRM_STATS=1 build (rm_shade.hpp: global atomics, very slow) and prints,
