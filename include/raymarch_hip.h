@@ -163,6 +163,14 @@ int rm_make_terrain_volume(rm_ctx* ctx, int rx, int ry, int rz, uint8_t* voxels_
  * The result becomes the resident volume; voxels_out (res^3 bytes) may be NULL. */
 int rm_voxelize_vertices(rm_ctx* ctx, const double* xyz, long long n_vertices, int res, int ks,
                          uint8_t* voxels_out);
+/* voxelize-scatter (meshvoxel.clj:25-43): mesh-scale as above; every vertex writes byte 64 into the 3x3x3 cells
+ * around a shifted copy of its cell ((x - dx + 0.4 res, y + 0.4 res, max(z - back, 0)) stored at index
+ * y*res^2 + z*res + x -- y and z swapped, as the reference writes it) and, with probability 1/4, into up to five such
+ * copies smeared along -x.  The reference draws dx / back / the copy count from the unseeded (rand); here draw k of
+ * vertex v is the counter-based uniform u(seed, v, k) documented in csrc/rm_volgen.hip, so the volume is a function
+ * of (vertices, res, seed) and can be checked.  The result becomes the resident volume; voxels_out may be NULL. */
+int rm_voxelize_scatter(rm_ctx* ctx, const double* xyz, long long n_vertices, int res, unsigned long long seed,
+                        uint8_t* voxels_out);
 /* make-heatmap (meshvoxel.clj:73-87): a res x res ARGB image (row-major, as piksel's
  * get-pixels returns it) -> in slab y a column of ceil(h) voxels of byte 255 over
  * pixel (x, y), h = c > 0 ? (c > 224 ? 2 : max(2, c*amp)) : 0 with c = argb & 255.

@@ -85,3 +85,45 @@ def make_heatmap(pixels, amp):
                 vox[y * rxy + hh * res + x] = 255        # :84
                 hh += 1
     return vox
+
+
+def scatter_uniform(seed, vertex, k):
+    """Draw k of vertex `vertex`: the counter-based uniform in [0, 1) that stands in for the reference's unseeded
+    (rand) -- SplitMix64 finaliser of seed + golden * (16 * vertex + k + 1), top 53 bits (csrc/rm_volgen.hip)."""
+    m = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (vertex * 16 + k + 1)) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z = z ^ (z >> 31)
+    return (z >> 11) * 2.0 ** -53
+
+
+def voxelize_scatter(vertices, res, seed=0):
+    """meshvoxel.clj:25-43, loops as written; (rand) -> scatter_uniform in the reference's call order."""
+    vox = np.zeros(res ** 3, dtype=np.uint8)
+    rxy = res * res
+    f = mesh_scale(vertices, res)
+    for vi, v in enumerate(np.asarray(vertices, dtype=np.float64).reshape(-1, 3)):
+        x, y, z = (int(c) for c in f(v))                                     # :32
+        draw = 0
+
+        def rand(n=1.0):
+            nonlocal draw
+            u = scatter_uniform(seed, vi, draw)
+            draw += 1
+            return n * u                                                      # (rand n) = (* n (Math/random))
+        count = 1                                                             # :33  (range (if (< (rand) 0.25) (rand 5) 1)):
+        if rand() < 0.25:                                                     #      the test draws first, then (rand 5);
+            count = math.ceil(rand(5))                                        #      (range 3.7) = 0 1 2 3
+        for i in range(count):
+            dx = int(rand((i * res) / 10.0))                                  # :34  (int (rand (* (/ i 5) r2))), r2 = res/2
+            xx = int((x - dx) - (res * -0.4))                                 # :35  (int (- x dx (* res -0.4)))
+            zz = max(z - int((res * 0.5) * (0.125 * rand() + 0.125)), 0)      # :36
+            yy = y + res * 0.4                                                # :37  (a double)
+            for z3 in range(zz - 1, zz + 2):                                  # :38
+                for k in range(3):
+                    y3 = (yy - 1.0) + k                                       # :39  (range (dec y) (+ 2 y))
+                    for x3 in range(xx - 1, xx + 2):                          # :40
+                        if 0 <= z3 < res and 0 <= y3 < res and 0 <= x3 < res:  # :41
+                            vox[int(y3) * rxy + z3 * res + x3] = 64           # :42
+    return vox

@@ -50,7 +50,7 @@ EXPORTS = [
     "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_set_contract", "rm_synchronize", "rm_pin_host_buffer",
     "rm_unpin_host_buffer", "rm_set_volume", "rm_set_volume_device",
     "rm_invalidate_volume", "rm_share_volume", "rm_frame_device_full", "rm_last_table_build_ms",
-    "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_make_heatmap_volume",
+    "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_voxelize_scatter", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_frame_device_argb", "rm_resolve_device_argb", "rm_last_frame_breakdown",
@@ -193,6 +193,7 @@ def lib():
     L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
     L.rm_make_terrain_volume.argtypes = [_vp, _i, _i, _i, _vp]
     L.rm_voxelize_vertices.argtypes = [_vp, _vp, ctypes.c_longlong, _i, _i, _vp]
+    L.rm_voxelize_scatter.argtypes = [_vp, _vp, ctypes.c_longlong, _i, ctypes.c_ulonglong, _vp]
     L.rm_make_heatmap_volume.argtypes = [_vp, _vp, _i, ctypes.c_double, _vp]
     L.rm_render_image.argtypes = [_vp, _vp, _vp, _vp, _i]
     L.rm_render_image_range.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i]
@@ -319,6 +320,17 @@ class Context:
         out = np.zeros(res ** 3, dtype=np.uint8) if want_host_copy else None
         check(lib().rm_voxelize_vertices(self._h, v.ctypes.data if v.size else None, v.shape[0], res, int(ks),
                                          out.ctypes.data if want_host_copy else None))
+        self.vres = (res, res, res)
+        return out
+
+    def voxelize_scatter(self, vertices, res, seed=0, want_host_copy=True):
+        """meshvoxel.clj voxelize-scatter with seeded draws on the device -> resident res^3 volume."""
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+        res = int(res)
+        out = np.zeros(res ** 3, dtype=np.uint8) if want_host_copy else None
+        check(lib().rm_voxelize_scatter(self._h, v.ctypes.data if v.size else None, v.shape[0], res,
+                                        ctypes.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                        out.ctypes.data if want_host_copy else None))
         self.vres = (res, res, res)
         return out
 

@@ -310,6 +310,25 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       pp_log2 = rmk::choose_pass_pack(run_end - i0, c->pass_pack, c->pack_waste);
     }
     i1 = std::min(run_end, i0 + (1 << pp_log2));  // one launch = what one wavefront holds
+    const size_t acc_bytes = out.row_major ? (size_t)n * 16
+                                           : (size_t)rmk::tiles_per_part(rmk::tiles_total(resx, n), out.tile_stride) * 64 * 16;
+    // A record that asks for more AO probes than a wavefront's exchange area holds results for (8: the
+    // reference's default is aoIter = 5 -> 6 probes) goes through the single-pass kernel, one launch per pass
+    // (each lane traces its own secondary rays there); the frame kernel carries no second AO path for it.
+    if (!sdf_frame && host_recs[i0].aoIter + 1 > 8) {
+      rmk::Accel accel;
+      int rc = ensure_accel(c, host_recs[i0].isoVal, &accel);
+      if (rc) return rc;
+      if (i0 == 0) HIP_TRY(hipMemsetAsync(out.acc, 0, acc_bytes, c->stream));
+      HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0,
+                                      resx, out.acc, n, 0, n, out.tile_first, out.tile_stride, !out.row_major, nullptr,
+                                      c->seed_cast, c->contract == RM_CONTRACT_GFX950));
+      launches++;
+      i0 = i0 + 1;
+      if (i0 == iter && out.argb && out.row_major)
+        HIP_TRY(rmk::launch_tonemap(c->stream, out.acc, d_opts, out.argb, n, c->contract == RM_CONTRACT_GFX950));
+      continue;
+    }
     rmk::FrameLaunch f;
     if (sdf_frame) {  // quality mode: no derived structures
       f.sdf = static_cast<const float*>(c->sdf_buf.p);
@@ -322,7 +341,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.opts_all = d_opts + i0;
     f.opts0 = d_opts;
     f.acc = out.acc;
-    f.argb = i1 == iter ? out.argb : nullptr;
+    f.argb = (i1 == iter && out.row_major) ? out.argb : nullptr;
     f.resx = resx; f.n = n; f.passes = i1 - i0;
     f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
     f.pp_log2 = pp_log2;
@@ -334,6 +353,11 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     launches++;
     i0 = i1;
   }
+  // a partition's TonemapImage words (rm_frame_device_argb): per pixel, so the order of the accumulators does not matter
+  if (out.argb && !out.row_major)
+    HIP_TRY(rmk::launch_tonemap(c->stream, out.acc, d_opts, out.argb,
+                                rmk::tiles_per_part(rmk::tiles_total(resx, n), out.tile_stride) * 64,
+                                c->contract == RM_CONTRACT_GFX950 && !sdf_frame));
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->timed = true;
   c->launches = launches;
@@ -701,8 +725,9 @@ int rm_make_terrain_volume(rm_ctx* c, int rx, int ry, int rz, uint8_t* voxels_ou
   return adopt_generated(c, rx, ry, rz, voxels_out);
 }
 
-int rm_voxelize_vertices(rm_ctx* c, const double* xyz, long long n_vertices, int res, int ks,
-                         uint8_t* voxels_out) {
+// ks >= 0 voxelize-ks, ks == -1 voxelize, scatter: voxelize-scatter with seeded draws
+static int voxelize_any(rm_ctx* c, const double* xyz, long long n_vertices, int res, int ks, bool scatter,
+                        unsigned long long seed, uint8_t* voxels_out) {
   int rc = check_ctx(c);
   if (rc) return rc;
   rc = check_res(res, res, res);
@@ -732,9 +757,23 @@ int rm_voxelize_vertices(rm_ctx* c, const double* xyz, long long n_vertices, int
     HIP_TRY(c->gen_buf.reserve((size_t)n_vertices * 24));
     HIP_TRY(hipMemcpyAsync(c->gen_buf.p, xyz, (size_t)n_vertices * 24, hipMemcpyHostToDevice, c->stream));
   }
-  HIP_TRY(rmk::launch_splat(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p),
-                            static_cast<const double*>(c->gen_buf.p), n_vertices, lo, off, s, res, ks));
+  if (scatter)
+    HIP_TRY(rmk::launch_scatter(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p),
+                                static_cast<const double*>(c->gen_buf.p), n_vertices, lo, off, s, res, seed));
+  else
+    HIP_TRY(rmk::launch_splat(c->stream, static_cast<uint8_t*>(c->vol->vox_buf.p),
+                              static_cast<const double*>(c->gen_buf.p), n_vertices, lo, off, s, res, ks));
   return adopt_generated(c, res, res, res, voxels_out);
+}
+
+int rm_voxelize_vertices(rm_ctx* c, const double* xyz, long long n_vertices, int res, int ks,
+                         uint8_t* voxels_out) {
+  return voxelize_any(c, xyz, n_vertices, res, ks, false, 0ull, voxels_out);
+}
+
+int rm_voxelize_scatter(rm_ctx* c, const double* xyz, long long n_vertices, int res, unsigned long long seed,
+                        uint8_t* voxels_out) {
+  return voxelize_any(c, xyz, n_vertices, res, -1, true, seed, voxels_out);
 }
 
 int rm_make_heatmap_volume(rm_ctx* c, const uint32_t* argb, int res, double amp, uint8_t* voxels_out) {

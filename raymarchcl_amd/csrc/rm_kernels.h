@@ -40,7 +40,7 @@ struct FrameLaunch {
   const RmOpts* opts_all = nullptr;  // record of the first pass of this launch (device)
   const RmOpts* opts0 = nullptr;     // record 0 of the frame (device): tonemap parameters
   float* acc = nullptr;            // float4 accumulators: tile-major [tiles_per_part][64], or the row-major image
-  uint32_t* argb = nullptr;        // nullable: TonemapImage output, written with the last pass (row-major image, or tile-major like acc)
+  uint32_t* argb = nullptr;        // row_major only, nullable: TonemapImage output, written with the last pass
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
@@ -72,6 +72,8 @@ hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz)
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 hipError_t launch_splat(hipStream_t st, uint8_t* d_out, const double* d_xyz, long long n,
                         const double p[3], const double off[3], double s, int res, int ks);
+hipError_t launch_scatter(hipStream_t st, uint8_t* d_out, const double* d_xyz, long long n,
+                          const double p[3], const double off[3], double s, int res, unsigned long long seed);
 hipError_t launch_heatmap(hipStream_t st, uint8_t* d_out, const uint32_t* d_argb, int res, double amp);
 hipError_t launch_filter_check(hipStream_t st, const float* d_rays, const RmOpts* d_opts, uint32_t* d_out, int n);
 hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, uint32_t* out,

@@ -223,9 +223,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   }
   if (first) {
     a.acc[at] = make_float4(px, py, pz, 1.0f);
-    // (row-major image: at the work-item id; a partition: tile-major next to its accumulators --
-    //  the 4-byte-per-pixel exchange unit of frames whose caller wants the ARGB image only)
-    if (a.argb) a.argb[a.row_major ? (long long)id : at] = tonemap_argb<M>(px, py, pz, a.opts0->gamma);
+    if (a.argb) a.argb[id] = tonemap_argb<M>(px, py, pz, a.opts0->gamma);
   }
 }
 

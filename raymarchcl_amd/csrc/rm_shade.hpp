@@ -910,7 +910,7 @@ struct Tracer {
     const int np = o.aoIter + 1;
     const Deal dl = deal(active);
     if (dl.owners == 0) return 1.0f;
-    if (np > kWaveLdsRes) return active ? occlusion(s, pos, normal) : 1.0f;  // (uniform) too many probes to post
+    // (np <= kWaveLdsRes: the host sends frames whose records ask for more probes through the single-pass kernels)
     const uint32_t seed0 =
         seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
     if (active) {

@@ -75,6 +75,52 @@ __global__ __launch_bounds__(256) void splat_kernel(uint8_t* __restrict__ out,
   }
 }
 
+// voxelize-scatter (meshvoxel.clj:25-43) with its random draws SEEDED.  The reference calls (rand) -- Math/random,
+// unseeded -- in a fixed order per vertex: one draw decides (p < 0.25) whether the vertex is smeared, a second how many
+// copies (range (rand 5)), then per copy i one draw for the x shift (rand (* (/ i 5) r2)) and one for the z shift.  Here
+// draw k of vertex v is a counter-based uniform u(seed, v, k) in [0,1) (SplitMix64 finaliser, 53 bits), so every vertex
+// is independent of the others and the volume is a function of (vertices, res, seed).  Everything else is the
+// reference's arithmetic: binary64, (int ..) truncation, the bounds tests on the (double) y range, the index
+// y*res^2 + z*res + x (y and z swapped relative to the other voxelisers, :42), byte 64.
+__device__ __forceinline__ double scatter_uniform(unsigned long long seed, long long vertex, int k) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)vertex * 16ull + (unsigned long long)k + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * 0x1p-53;
+}
+__global__ __launch_bounds__(256) void scatter_kernel(uint8_t* __restrict__ out, const double* __restrict__ xyz,
+                                                      long long n, Splat sp, unsigned long long seed) {
+  const long long rxy = (long long)sp.res * sp.res;
+  const double dres = (double)sp.res;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n;
+       v += (long long)gridDim.x * blockDim.x) {
+    const int x0 = d2i(sp.ox + (xyz[3 * v + 0] - sp.px) * sp.s);
+    const int y0 = d2i(sp.oy + (xyz[3 * v + 1] - sp.py) * sp.s);
+    const int z0 = d2i(sp.oz + (xyz[3 * v + 2] - sp.pz) * sp.s);
+    int copies = 1, draw = 1;                                   // (range (if (< (rand) 0.25) (rand 5) 1)): draws are
+    if (scatter_uniform(seed, v, 0) < 0.25) {                   // numbered in the reference's call order, so the copy
+      copies = (int)ceil(5.0 * scatter_uniform(seed, v, 1));    // count consumes draw 1 only when it is asked for
+      draw = 2;
+    }
+    for (int i = 0; i < copies; i++) {
+      const double span = (double)((long long)i * sp.res) / 10.0;   // (* (/ i 5) r2), r2 = res/2: the rational i*res/10
+      const int dx = d2i(span * scatter_uniform(seed, v, draw + 2 * i));
+      const int x = d2i((double)(x0 - dx) - dres * -0.4);          // (int (- x dx (* res -0.4)))
+      const int back = d2i((dres * 0.5) * (0.125 * scatter_uniform(seed, v, draw + 2 * i + 1) + 0.125));
+      const int z = max(z0 - back, 0);
+      const double y = (double)y0 + dres * 0.4;                     // (+ y (* res 0.4)): a double from here on
+      for (int zz = z - 1; zz < z + 2; zz++)
+        for (int k = 0; k < 3; k++) {
+          const double yy = (y - 1.0) + (double)k;                  // (range (dec y) (+ 2 y)): y-1, y, y+1
+          for (int xx = x - 1; xx < x + 2; xx++)
+            if (zz >= 0 && zz < sp.res && yy >= 0.0 && yy < dres && xx >= 0 && xx < sp.res)
+              out[(long long)d2i(yy) * rxy + (long long)zz * sp.res + xx] = 64;
+        }
+    }
+  }
+}
+
 // pixel (x, y) of a res x res image -> a column of ceil(h) voxels in slab y:
 //   c = argb & 255;  h = c > 0 ? (c > 224 ? 2 : max(2, c*amp)) : 0;  voxels[y*rxy + hh*res + x] = -1
 __global__ __launch_bounds__(256) void heatmap_kernel(uint8_t* __restrict__ out,
@@ -118,6 +164,15 @@ hipError_t launch_splat(hipStream_t st, uint8_t* d_out, const double* d_xyz, lon
   if (e != hipSuccess || n == 0) return e;
   const Splat sp{p[0], p[1], p[2], off[0], off[1], off[2], s, res, ks};
   splat_kernel<<<blocks_for(n), 256, 0, st>>>(d_out, d_xyz, n, sp);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter(hipStream_t st, uint8_t* d_out, const double* d_xyz, long long n,
+                          const double p[3], const double off[3], double s, int res, unsigned long long seed) {
+  hipError_t e = hipMemsetAsync(d_out, 0, (size_t)res * res * res, st);
+  if (e != hipSuccess || n == 0) return e;
+  const Splat sp{p[0], p[1], p[2], off[0], off[1], off[2], s, res, 0};
+  scatter_kernel<<<blocks_for(n), 256, 0, st>>>(d_out, d_xyz, n, sp, seed);
   return hipGetLastError();
 }
 

@@ -69,6 +69,17 @@ def voxelize_ks(vertices, res, ks, ctx=None):
             c.close()
 
 
+def voxelize_scatter(vertices, res, seed=0, ctx=None):
+    """meshvoxel.clj:25-43 with the reference's unseeded (rand) draws replaced by a counter-based
+    uniform of (seed, vertex, draw) -- csrc/rm_volgen.hip scatter_kernel; byte 64, index y*res^2 + z*res + x."""
+    c = _ctx(ctx)
+    try:
+        return c.voxelize_scatter(vertices, res, seed=seed)
+    finally:
+        if ctx is None:
+            c.close()
+
+
 def make_heatmap(pixels, amp, ctx=None):
     """meshvoxel.clj:73-87 from the image's ARGB pixels (uint32 [res, res], what
     pix/get-pixels returns for the square image the reference loads)."""

@@ -363,3 +363,36 @@ def test_randomised_parity_smoke():
         assert mod.main() == 0
     finally:
         sys.argv = argv
+
+
+@pytest.mark.parametrize("ao_iter", [7, 8, 11])
+def test_records_with_more_ao_probes_than_a_wavefront_exchanges(native, oracle_mod, ao_iter):
+    """aoIter + 1 probes per hit: up to 8 the wave-shared AO phase of the frame kernel posts them; beyond, the
+    library renders the frame through the single-pass kernels (every lane traces its own probes).  Both routes
+    equal the oracle, also as partitions inside the library and in the device-resident form."""
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen, structs
+
+    it, w, h = 3, 40, 28
+    recs = []
+    for i in range(it):
+        o = rm.render_options(width=w, height=h, vres=[64, 64, 64], t=i * 0.333, iter=it,
+                              eyepos=rm.compute_eyepos(-45, 2.25, 0.35), targetpos=[0, -0.4, 0], mat="orange-stripes")
+        o["aoIter"] = ao_iter
+        o["aoStepDist"] = 0.03
+        recs.append(structs.encode_bytes(o))
+    opts = b"".join(recs)
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=50 + i) for i in range(it)])
+    vox = scenes.volume("gyroid", 64)
+    n = w * h
+    want, want_argb = oracle_mod.render_frame(vox, opts, mc, n)
+    with native.Context(0) as ctx:
+        ctx.set_volume(vox, (64, 64, 64))
+        px, argb = ctx.render_frame(opts, mc, n)
+    assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb)
+    with native.Context([0, 0, 0]) as ctx:
+        ctx.set_volume(vox, (64, 64, 64))
+        px, argb = ctx.render_frame(opts, mc, n)
+        assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb)
+        _none, argb2 = ctx.render_frame(opts, mc, n, want_pixels=False)
+        assert np.array_equal(argb2, want_argb)

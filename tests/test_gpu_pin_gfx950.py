@@ -119,7 +119,7 @@ def test_config2_full_size_against_the_references_own_build(refs, native):
     vox, vres, opts, mc = bench.build_inputs(wl)
     n = wl["w"] * wl["h"]
     px = {b: refs.gfx950_render_frame(vox, opts, mc, n, build=b, tonemap=False)[0] for b in refs.GFX950_BUILDS}
-    with native.Context(0) as ctx:  # library default: RM_CONTRACT_GFX950
+    with native.Context(0, contract="gfx950") as ctx:  # (= the library default; this module's fixture switches unnamed contexts to "cpu")
         ctx.set_volume(vox, vres)
         got, _ = ctx.render_frame(opts, mc, n, want_argb=False)
     stable = (rel(px["fast"], px["strict"]) <= 1e-4) & (rel(px["fast"], px["default"]) <= 1e-4) & \

@@ -75,3 +75,17 @@ def test_heatmap_matches_restatement(gpu_ctx):
     px[0, 0] = 0xFFABCDE1  # > 224
     for amp in (0.0, 0.03125, float(np.float32(7 / (10 * 1.33333))), 0.75):
         assert np.array_equal(gpu_ctx.make_heatmap_volume(px, amp), vg.make_heatmap(px, amp))
+
+
+@pytest.mark.parametrize("res,seed", [(32, 0), (48, 12345), (33, 7)])
+def test_seeded_scatter_voxeliser_matches_restatement(gpu_ctx, res, seed):
+    """voxelize-scatter (meshvoxel.clj:25-43) with seeded draws: device kernel == the loop-by-loop restatement."""
+    verts = _cloud(11, 3000)
+    got = gpu_ctx.voxelize_scatter(verts, res, seed=seed)
+    want = vg.voxelize_scatter(verts, res, seed=seed)
+    assert got.dtype == np.uint8 and set(np.unique(got)) <= {0, 64}
+    assert np.array_equal(got, want)
+    assert 0 < int((got == 64).sum()) < res ** 3
+    if seed:
+        assert not np.array_equal(got, gpu_ctx.voxelize_scatter(verts, res, seed=seed + 1))  # the draws matter
+    assert not gpu_ctx.voxelize_scatter(np.zeros((0, 3)), 8, seed=1).any()

@@ -78,3 +78,25 @@ def test_binary_and_ascii_stl_reader(tmp_path):
     a.write_text("solid x\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\n"
                  "endloop\nendfacet\nendsolid x\n")
     assert np.array_equal(meshvoxel.load_mesh(str(a)), tris[0])
+
+
+def test_scatter_restatement_properties():
+    """voxelize-scatter restatement: deterministic in the seed, byte 64 only, the y/z swap of the reference's
+    index (meshvoxel.clj:42), the +0.4 res shifts, and ~1/4 of the vertices smeared into several copies."""
+    import oracle.volgen_np as vg
+
+    res = 40
+    one = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 0.25, 0.75]])
+    a, b = vg.voxelize_scatter(one, res, seed=3), vg.voxelize_scatter(one, res, seed=3)
+    assert np.array_equal(a, b) and set(np.unique(a)) <= {0, 64}
+    # vertex 2 scales to (20, 10, 30): its unsmeared copy is centred on x = 20 + 16, y-slab 10 + 16, z = 30 - back
+    f = vg.mesh_scale(one, res)
+    x, y, z = (int(c) for c in f(one[2]))
+    assert (x, y, z) == (20, 10, 30)
+    grid = a.reshape(res, res, res)  # [y][z][x] by the reference's index
+    ys, zs, xs = np.nonzero(grid)
+    assert ys.min() >= y + 16 - 1 - 16 and (grid[y + 16 - 1:y + 16 + 2].any())
+    # uniforms: in [0, 1), reproducible, and a quarter of them below 0.25
+    u = np.array([vg.scatter_uniform(9, v, 0) for v in range(4000)])
+    assert (u >= 0).all() and (u < 1).all() and abs((u < 0.25).mean() - 0.25) < 0.03
+    assert vg.scatter_uniform(9, 5, 2) == vg.scatter_uniform(9, 5, 2) != vg.scatter_uniform(9, 5, 3)
