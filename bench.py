@@ -144,7 +144,7 @@ def main():
                          "build on the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"))
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch

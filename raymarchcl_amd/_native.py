@@ -27,8 +27,8 @@ DEVICE_LIBS = ["opencl.bc", "ocml.bc", "ockl.bc", "oclc_daz_opt_off.bc", "oclc_u
 # -disable-machine-sink / -disable-machine-licm: with these two machine-level code motion passes on,
 # the greedy VGPR allocator of this compiler (ROCm 7.2 clang 22) produces instantiations of the frame
 # kernel that render wrong pixels (shadow results of the wave-shared phases go missing) depending on
-# the register budget -- reproduced, bisected and described in DESIGN.md section 4c
-# (tools/repro_gpucast_fault.sh).  Cost of switching them off: 0-4 % of the frame time.
+# the register budget -- reproduced, bisected and described in DESIGN_HISTORY.md section 4c
+# (reproducer: tools/repro_gpucast_fault.sh of commit c80bec6).  Cost of switching them off: 0-4 % of the frame time.
 # (the ROCm tree comes from ROCM_PATH / HIPCC like hipcc's own; the code-object version is spelled out so
 #  that it cannot drift away from the oclc_abi_version_600 bitcode named above)
 ROCM_PATH = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -97,7 +97,7 @@ def _stale():
 def build(force=False, verbose=False, lint=None):
     """hipcc cross-compiles for gfx950 without a GPU; the .so stays in-tree.  A real compile of the
     PRODUCT library is followed by lint_kernels() (the generated code must be free of the compiler
-    fault of DESIGN.md 4c; ~35 s): a library that fails it is removed again and the call raises.
+    fault of DESIGN_HISTORY.md 4c; ~35 s): a library that fails it is removed again and the call raises.
     lint=False skips that (A/B variants: RAYMARCH_LIB names another file)."""
     if not force and not _stale():
         return LIB_PATH
@@ -118,7 +118,7 @@ def build(force=False, verbose=False, lint=None):
 
 def lint_kernels():
     """Compile the kernels to gfx950 assembly with the product flags and look for the two shapes
-    of the compiler fault DESIGN.md 4c describes: a spill reload or an allocator-inserted copy in a
+    of the compiler fault DESIGN_HISTORY.md 4c describes: a spill reload or an allocator-inserted copy in a
     block that is entered with exec = 0 (isa_exec_lint.py of this package), and spilled SGPRs.  Raises RmError if either is present --
     a library built from such code renders wrong or faults in some instantiations, silently.
     (build() runs this after every real compile of the product library; tests/test_isa_budget.py too; ~35 s, no GPU.)"""
@@ -144,7 +144,7 @@ def lint_kernels():
     sgpr = [m.group(1) for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*?)\.sgpr_spill_count:\s+(\d+)", text, re.S)
             if int(m.group(2)) > 0]
     if fatal or sgpr:
-        raise RmError(-3, f"kernel build hits the compiler fault of DESIGN.md 4c: vector instructions under exec = 0: {fatal[:4]}; "
+        raise RmError(-3, f"kernel build hits the compiler fault of DESIGN_HISTORY.md 4c: vector instructions under exec = 0: {fatal[:4]}; "
                           f"kernels with spilled SGPRs: {sgpr[:4]}")
     return len(list(isa_exec_lint.kernels(lines)))
 

@@ -38,8 +38,8 @@ RM_DEV uint32_t f2u_gpu(float x) {
   // what v_cvt_u32_f32 does -- truncate, saturate to [0, 2^32 - 1], NaN -> 0 -- written so that no
   // C cast is out of range (the compiler folds the comparisons around one v_cvt_u32_f32)
   // (The instruction itself through inline asm -- asm("v_cvt_u32_f32 %0, %1") -- computes the same value; that
-  //  spelling was the round's first reproducer of the compiler fault of DESIGN.md 4c, see
-  //  tools/repro_gpucast_fault.sh and git commit 11be60c.)
+  //  spelling was the round's first reproducer of the compiler fault of DESIGN_HISTORY.md 4c, see
+  //  tools/repro_gpucast_fault.sh in the tree of git commit 11be60c.)
   return x > 0.0f ? (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x) : 0u;
 }
 RM_DEV uint32_t f2u(float x) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Lint for one code-generation fault of the compiler: a register-allocator RELOAD of a
+"""Lint for one code-generation fault of the compiler (DESIGN_HISTORY.md 4c): a register-allocator RELOAD of a
 spilled VGPR placed in a block that runs under a narrowed exec mask, directly in front of the
 instruction that widens the mask again.
 

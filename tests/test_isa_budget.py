@@ -67,7 +67,7 @@ def test_launch_resources_of_the_default_kernel(frame_kernel_asm, key):
 
 
 def test_no_spill_reload_in_a_block_entered_with_exec_zero(frame_kernel_asm):
-    """The code-generation fault DESIGN.md 4c pins down (round 3, with rocgdb): the register allocator puts
+    """The code-generation fault DESIGN_HISTORY.md 4c pins down (round 3, with rocgdb): the register allocator puts
     the reload of a spilled VGPR into the exit block of a loop it lowered as divergent -- a block entered
     through `s_cbranch_execz`, with NO lane enabled, in front of the `s_or_b64 exec` that brings the lanes
     back.  The reload reaches nobody; the lanes go on with whatever the loop used the register for (seen:

@@ -29,11 +29,13 @@ j = json.load(open(p))
 j["source_digest"] = bench.source_digest()
 json.dump(j, open(p, "w"), indent=1)
 # the bench line below reads it from profiles/
-json.dump(j, open(os.path.join(R, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
+json.dump(j, open(os.path.join(R, "profiles", "r04_pmc_traffic.json"), "w"), indent=1)
 PY
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 for w in c1 c3 c4 c5; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1; done > $OUT/other_workloads.txt
 python tools/part_timing.py --frames-in-flight 2 --reps 30 > $OUT/part_timing.txt 2>&1
+BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/rehearsal_ranks2.json 2>/dev/null
+BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --backend library --steps 5 --warmup 2 > $OUT/rehearsal_library2.json 2>/dev/null
 python tools/sdf_bench.py > $OUT/sdf_bench.txt 2>&1
 rm -rf $OUT/pmc/p*/pmc_results.db
 head -c 700 $OUT/bench_line.json; echo; tail -3 $OUT/part_timing.txt; head -6 $OUT/kernel_stats.txt
