@@ -1,4 +1,4 @@
-for o in 0 1 2 0 1 2; do echo -n "row order $o: "; RAYMARCH_ROW_ORDER=$o python bench.py --steps 30 --warmup 3 --no-cpu-baseline --frames-in-flight 1 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | head -2 | tr '\n' ' '; echo; done
-for o in 0 2; do echo -n "row order $o, 3 in flight: "; RAYMARCH_ROW_ORDER=$o python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | head -2 | tr '\n' ' '; echo; done
-RAYMARCH_ROW_ORDER=2 python -m pytest tests/test_gpu_device_contract.py tests/test_gpu_configs.py -m gpu -q -x 2>&1 | tail -2
-for w in c3 c5; do for o in 0 2; do echo -n "$w order $o "; RAYMARCH_ROW_ORDER=$o python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' '; echo; done; done
+mkdir -p gpurun_out/r4j
+export RAYMARCH_SKIP_LINT=1
+(WL=c5 STEPS=6 bash tools/ab_time.sh; WL=c3 STEPS=10 bash tools/ab_time.sh) > gpurun_out/r4j/c5_waves.txt 2>&1
+cat gpurun_out/r4j/c5_waves.txt
