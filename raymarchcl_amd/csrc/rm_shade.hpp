@@ -139,12 +139,6 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 //      shift-ors, the bounds test one compare of the or-ed coordinates, and the table is read
 //      through a buffer descriptor with a 32-bit offset (no 64-bit address arithmetic per
 //      fetch; out-of-range offsets read 0, so the fetch needs no guard)
-#ifndef RM_LOOKAHEAD
-#define RM_LOOKAHEAD 0
-#endif
-#ifndef RM_X_MCSMALL
-#define RM_X_MCSMALL 0
-#endif
 struct WalkTab {
   const uint8_t* __restrict__ dist8;   // table 0; tables 1..8 follow at oct_stride
   __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2: all nine tables as one buffer
@@ -156,64 +150,6 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
                      int* cell_out, unsigned long long table_off) {
   int d, j;
   unsigned cell;
-#if RM_LOOKAHEAD
-  if (LAYOUT == 2) {
-    // EXPERIMENT (-DRM_LOOKAHEAD=1): the table values of this sample AND of the next one are fetched together; a lane
-    // whose skip is a single sample decides the next sample in the same wave-level trip (one fetch latency for both).
-    // Per lane the sequence of decisions, adds and positions is the sequential one.
-    const int qx = M::cell(p.x), qy = M::cell(p.y), qz = M::cell(p.z);
-    const bool ok0 = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < tab.res) & (steps > 0);
-    const unsigned cell0 = ((((unsigned)qz << tab.sh) | (unsigned)qy) << tab.sh) | (unsigned)qx;
-    const v3 p1 = p + delta;
-    const int rx = M::cell(p1.x), ry = M::cell(p1.y), rz = M::cell(p1.z);
-#if RM_LOOKAHEAD == 2
-    // (sample 1 outside the grid: its cell becomes an offset beyond the buffer -- the fetch returns 0 -- and the
-    //  outcome is read back from the cell after the fetch, so that no lane mask lives across it)
-    const unsigned cell1 = ((((unsigned)rx | (unsigned)ry) | (unsigned)rz) < tab.res)
-                               ? (((((unsigned)rz << tab.sh) | (unsigned)ry) << tab.sh) | (unsigned)rx) : 0xf0000000u;
-#else
-    const bool ok1 = (((unsigned)rx | (unsigned)ry) | (unsigned)rz) < tab.res;  // (its steps > 0 follows from j0 = 1 < steps)
-    const unsigned cell1 = ((((unsigned)rz << tab.sh) | (unsigned)ry) << tab.sh) | (unsigned)rx;
-#endif
-    const int d0 = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell0 + (unsigned)table_off, 0, 0);
-#if RM_LOOKAHEAD == 2
-    const int d1 = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell1 < 0xf0000000u ? cell1 + (unsigned)table_off : cell1, 0, 0);
-    const bool ok1 = cell1 < 0xf0000000u;
-#else
-    const int d1 = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell1 + (unsigned)table_off, 0, 0);
-#endif
-    const int j0 = max((int)__builtin_fmaf((float)d0, inv_s, c0), 1);
-    const bool hit0 = ok0 & (d0 == 0);
-    const bool go0 = ok0 & (d0 != 0) & (j0 < steps);
-    *cell_out = (int)cell0;
-    if (!go0) return hit0 ? 1 : 2;
-    p = p + delta;  // (the same add as p1: recomputed so that p1 does not live across the fetch)
-    steps -= j0;
-    int k = j0 - 1;
-    if (j0 == 1) {
-      const int j1 = max((int)__builtin_fmaf((float)d1, inv_s, c0), 1);
-      const bool hit1 = ok1 & (d1 == 0);
-      const bool go1 = ok1 & (d1 != 0) & (j1 < steps);
-      *cell_out = (int)cell1;
-      if (!go1) return hit1 ? 1 : 2;
-      k = j1;
-      steps -= j1;
-    }
-    while (k >= 4) {
-      p = p + delta;
-      p = p + delta;
-      p = p + delta;
-      p = p + delta;
-      k -= 4;
-    }
-    if (k & 2) {
-      p = p + delta;
-      p = p + delta;
-    }
-    if (k & 1) p = p + delta;
-    return 0;
-  }
-#endif
   if (LAYOUT == 2) {
     // (M::cell: the bare conversion instruction; scene_distance has applied M::walk_guard)
     // p and delta are in CELL units in this layout: the reference's p * res (renderer.cl:165) with res a
@@ -332,9 +268,6 @@ struct Tracer {
   // scatter table lookup: renderer.cl:142-144
   RM_DEV float4 table(uint32_t seed) {
     if (COUNT) cnt.mc_reads++;
-#if RM_X_MCSMALL == 1
-    return mc_[seed & 63u];  // TIMING PROBE (wrong pixels): every scatter-table read hits L1
-#endif
     return mc_[seed & (RM_TABLE_ENTRIES - 1)];
   }
 
@@ -1008,11 +941,7 @@ struct Tracer {
           dj += o.aoStepDist;
           if (j == probe) d = dj;
         }
-#if RM_X_MCSMALL
-        const float4 r = tab[seed & 63u];  // TIMING PROBE (wrong pixels)
-#else
         const float4 r = tab[seed & (RM_TABLE_ENTRIES - 1)];
-#endif
         const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, onrm));
         float sd, scode;
         v3 nn;
