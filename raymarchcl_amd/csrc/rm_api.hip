@@ -984,6 +984,8 @@ int rm_set_sdf_volume(rm_ctx* c, const float* sdf, int rx, int ry, int rz) {
   rc = check_res(rx, ry, rz);
   if (rc) return rc;
   if (rx < 2 || ry < 2 || rz < 2) return fail(RM_EINVAL, "a distance field needs at least 2 cells per axis");
+  if (rx > 4096 || ry > 4096 || rz > 4096 || (unsigned long long)rx * ry * rz >= (1ull << 32))
+    return fail(RM_EINVAL, "distance field %dx%dx%d: at most 4096 cells per axis and fewer than 2^32 cells", rx, ry, rz);
   const size_t bytes = (size_t)rx * ry * rz * 4;
   HIP_TRY(c->sdf_buf.reserve(bytes));
   HIP_TRY(hipMemcpyAsync(c->sdf_buf.p, sdf, bytes, hipMemcpyHostToDevice, c->stream));

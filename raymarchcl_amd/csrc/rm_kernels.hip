@@ -451,6 +451,9 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
 #ifndef RM_FRAME_MINW
 #define RM_FRAME_MINW 7
 #endif
+#ifndef RM_SDF_MINW
+#define RM_SDF_MINW 4  // (quality mode)
+#endif
 #define RM_FRAME(A, W, S, B, G) render_frame_kernel<A, W, S, B, G><<<grid, block, 0, st>>>(a)
 #define RM_FRAME_ARITH(A, W, S, B)                  \
   do {                                              \
@@ -460,7 +463,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   } while (0)
   a.log2res = f.accel.log2res;
   if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
-    if (f.arith == 1) RM_FRAME(false, 4, true, 0, 1); else RM_FRAME(false, 4, true, 0, 0);
+    if (f.arith == 1) RM_FRAME(false, RM_SDF_MINW, true, 0, 1); else RM_FRAME(false, RM_SDF_MINW, true, 0, 0);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
     RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 1);
   } else if (f.accel.dist && f.accel.surf && f.accel.log2res) {

@@ -317,14 +317,20 @@ struct Tracer {
     ix = min(ix, rx - 2); iy = min(iy, ry - 2); iz = min(iz, rz - 2);
     ix = max(ix, 0); iy = max(iy, 0); iz = max(iz, 0);
     const float fx = ux - (float)ix, fy = uy - (float)iy, fz = uz - (float)iz;
-    const int x1 = ix + 1 < rx ? ix + 1 : ix, y1 = iy + 1 < ry ? iy + 1 : iy, z1 = iz + 1 < rz ? iz + 1 : iz;
+    // The host admits fields of 2 .. 4096 cells per axis (rm_set_sdf_volume), so the upper neighbour of the clamped
+    // base cell always exists (x1 = ix + 1, ...) and a cell index fits 32 bits.  The two x-neighbours of a row are
+    // adjacent in memory: ONE 8-byte load per row, four per sample -- the kernel is bound by the L1's tag
+    // lookups (one per lane and load for rays this incoherent), which this halves.
     const float* __restrict__ g = sc.sdf;
-    const size_t r00 = ((size_t)iz * ry + iy) * rx, r10 = ((size_t)iz * ry + y1) * rx,
-                 r01 = ((size_t)z1 * ry + iy) * rx, r11 = ((size_t)z1 * ry + y1) * rx;
-    const float a00 = g[r00 + ix] + (g[r00 + x1] - g[r00 + ix]) * fx;
-    const float a10 = g[r10 + ix] + (g[r10 + x1] - g[r10 + ix]) * fx;
-    const float a01 = g[r01 + ix] + (g[r01 + x1] - g[r01 + ix]) * fx;
-    const float a11 = g[r11 + ix] + (g[r11 + x1] - g[r11 + ix]) * fx;
+    const unsigned r00 = __umul24(__umul24((unsigned)iz, (unsigned)ry) + (unsigned)iy, (unsigned)rx) + (unsigned)ix;
+    const unsigned sy = (unsigned)rx, sz = __umul24((unsigned)ry, (unsigned)rx);
+    typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
+    const pair_t t00 = *reinterpret_cast<const pair_t*>(g + r00), t10 = *reinterpret_cast<const pair_t*>(g + (r00 + sy));
+    const pair_t t01 = *reinterpret_cast<const pair_t*>(g + (r00 + sz)), t11 = *reinterpret_cast<const pair_t*>(g + (r00 + sz + sy));
+    const float a00 = t00.x + (t00.y - t00.x) * fx;
+    const float a10 = t10.x + (t10.y - t10.x) * fx;
+    const float a01 = t01.x + (t01.y - t01.x) * fx;
+    const float a11 = t11.x + (t11.y - t11.x) * fx;
     const float b0 = a00 + (a10 - a00) * fy;
     const float b1 = a01 + (a11 - a01) * fy;
     return b0 + (b1 - b0) * fz;
@@ -338,26 +344,36 @@ struct Tracer {
                    M::clamp(p.z, o.voxelBoundsMin[2], o.voxelBoundsMax[2]));
     return sdf_sample(q) + length(p - q);
   }
-  RM_DEV void scene_distance_sdf(v3 rpos, v3 dir, float& dist, float& code, v3& nrm) {
+  // gradient of the field at a position (central differences over one voxelSize)
+  RM_DEV v3 sdf_gradient(v3 rpos) {
+    const float e = sc.o->voxelSize;
+    const v3 g = V(sdf_volume(V(rpos.x + e, rpos.y, rpos.z)) - sdf_volume(V(rpos.x - e, rpos.y, rpos.z)),
+                   sdf_volume(V(rpos.x, rpos.y + e, rpos.z)) - sdf_volume(V(rpos.x, rpos.y - e, rpos.z)),
+                   sdf_volume(V(rpos.x, rpos.y, rpos.z + e)) - sdf_volume(V(rpos.x, rpos.y, rpos.z - e)));
+    return normalize(g);
+  }
+  // grad_later: nullptr = the normal of an estimate that is close enough to be the hit is computed here;
+  // otherwise *grad_later says that it IS the gradient at rpos and leaves computing it to the caller (a march
+  // keeps only its LAST estimate's normal, renderer.cl:244-246: six more field samples once per march instead
+  // of in every turn in which some lane of the wavefront is within 2 eps)
+  RM_DEV void scene_distance_sdf(v3 rpos, v3 dir, float& dist, float& code, v3& nrm, bool* grad_later = nullptr) {
     const RmOpts& o = *sc.o;
     const float h = rpos.y + o.groundY;
     float rd, rc;
     if (h < 1e5f) { rd = h; rc = h; } else { rd = 1e5f; rc = -1.0f; }
     nrm = (rd < 1e5f) ? V(0.f, 1.f, 0.f) : -dir;
     const float dv = sdf_volume(rpos);
+    bool later = false;
     if (dv < rd) {
       rd = dv;
       rc = 1.0f;
+      nrm = -dir;
       if (dv <= o.eps * 2.0f) {  // close enough to be the hit: gradient by central differences
-        const float e = o.voxelSize;
-        const v3 g = V(sdf_volume(V(rpos.x + e, rpos.y, rpos.z)) - sdf_volume(V(rpos.x - e, rpos.y, rpos.z)),
-                       sdf_volume(V(rpos.x, rpos.y + e, rpos.z)) - sdf_volume(V(rpos.x, rpos.y - e, rpos.z)),
-                       sdf_volume(V(rpos.x, rpos.y, rpos.z + e)) - sdf_volume(V(rpos.x, rpos.y, rpos.z - e)));
-        nrm = normalize(g);
-      } else {
-        nrm = -dir;
+        if (grad_later) later = true;
+        else nrm = sdf_gradient(rpos);
       }
     }
+    if (grad_later) *grad_later = later;
     dist = rd;
     code = rc;
   }
@@ -429,8 +445,8 @@ struct Tracer {
                              v3& nrm, bool known_inside = false, int walk_limit = 0x7fffffff,
                              bool* cut = nullptr) {
     const RmOpts& o = *sc.o;
-    if (SDFM) {
-      scene_distance_sdf(rpos, dir, dist, code, nrm);
+    if (SDFM) {  // (`cut` doubles as "the normal is the gradient, not computed yet")
+      scene_distance_sdf(rpos, dir, dist, code, nrm, cut);
       return;
     }
     if (COUNT) cnt.dts_calls++;
@@ -673,6 +689,7 @@ struct Tracer {
         float sd2, sc2;
         scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
       }
+      if (SDFM && last_kind == 1 && cut_last) r.normal = sdf_gradient(r.pos);  // (r.pos is the last estimate's position, bit for bit)
       if (last_kind == 0) {  // renderer.cl:211-212 for the ground / sky term
         const float h = (rdir.y * last_t + ro.y) + o.groundY;
         scode = h < 1e5f ? h : -1.0f;
