@@ -90,7 +90,7 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::shared_ptr<Volume> vol;
-  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf;
+  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, sdfq_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
@@ -331,7 +331,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     }
     rmk::FrameLaunch f;
     if (sdf_frame) {  // quality mode: no derived structures
-      f.sdf = static_cast<const float*>(c->sdf_buf.p);
+      f.sdf = static_cast<const float*>(c->sdfq_buf.p);
     } else {
       int rc = ensure_accel(c, host_recs[i0].isoVal, &f.accel);
       if (rc) return rc;
@@ -505,7 +505,7 @@ void rm_destroy(rm_ctx* c) {
   for (const void* h : c->host_bufs) (void)hipHostUnregister(const_cast<void*>(h));
   c->host_bufs.clear();
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
-                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->atile_buf};
+                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->sdfq_buf, &c->atile_buf};
   for (DevBuf* b : bufs) b->release();
   c->vol.reset();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -989,6 +989,9 @@ int rm_set_sdf_volume(rm_ctx* c, const float* sdf, int rx, int ry, int rz) {
   const size_t bytes = (size_t)rx * ry * rz * 4;
   HIP_TRY(c->sdf_buf.reserve(bytes));
   HIP_TRY(hipMemcpyAsync(c->sdf_buf.p, sdf, bytes, hipMemcpyHostToDevice, c->stream));
+  // what the kernel samples: one float4 per cell (4x the field; built once here)
+  HIP_TRY(c->sdfq_buf.reserve(bytes * 4));
+  HIP_TRY(rmk::launch_sdf_quads(c->stream, static_cast<const float*>(c->sdf_buf.p), rx, ry, rz, static_cast<float*>(c->sdfq_buf.p)));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->sdf_rx = rx; c->sdf_ry = ry; c->sdf_rz = rz;
   return RM_OK;

@@ -35,7 +35,7 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel,
 struct FrameLaunch {
   const uint8_t* vox = nullptr;
   Accel accel;
-  const float* sdf = nullptr;      // quality mode: float distance field instead of vox / accel
+  const float* sdf = nullptr;      // quality mode: the distance field as float4 xy-faces (launch_sdf_quads) instead of vox / accel
   const float* mc_all = nullptr;   // table of the first pass of this launch (device)
   const RmOpts* opts_all = nullptr;  // record of the first pass of this launch (device)
   const RmOpts* opts0 = nullptr;     // record 0 of the frame (device): tonemap parameters
@@ -68,6 +68,8 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                          uint8_t* d_dist9, bool bricked = false);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
+// quality mode: float field -> one float4 per cell (the cell's xy-face at its layer), rm_accel.hip
+hipError_t launch_sdf_quads(hipStream_t st, const float* d_field, int rx, int ry, int rz, float* d_quads);
 // rm_volgen.hip: the other volume producers of the reference, on the device
 hipError_t launch_terrain(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 hipError_t launch_splat(hipStream_t st, uint8_t* d_out, const double* d_xyz, long long n,

@@ -30,7 +30,7 @@ struct Scene {
   const uint8_t* __restrict__ dist;   // rm_accel.hip dist8, or nullptr
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
   unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
-  const float* __restrict__ sdf = nullptr;  // quality mode: float distance field (Tracer<.., SDFM = true>)
+  const float* __restrict__ sdf = nullptr;  // quality mode: the distance field, one float4 xy-face per cell (Tracer<.., SDFM = true>)
   int seed_cast_gpu = 0;  // (uint) casts of the seed expressions as a GPU device lowers them (rm_set_seed_cast)
   unsigned log2res = 0;   // LAYOUT 2 (walk_step): edge of the cubic grid = 1 << log2res
 };
@@ -318,19 +318,17 @@ struct Tracer {
     ix = max(ix, 0); iy = max(iy, 0); iz = max(iz, 0);
     const float fx = ux - (float)ix, fy = uy - (float)iy, fz = uz - (float)iz;
     // The host admits fields of 2 .. 4096 cells per axis (rm_set_sdf_volume), so the upper neighbour of the clamped
-    // base cell always exists (x1 = ix + 1, ...) and a cell index fits 32 bits.  The two x-neighbours of a row are
-    // adjacent in memory: ONE 8-byte load per row, four per sample -- the kernel is bound by the L1's tag
-    // lookups (one per lane and load for rays this incoherent), which this halves.
-    const float* __restrict__ g = sc.sdf;
+    // base cell always exists and a cell index fits 32 bits.  sc.sdf holds one float4 per cell: the four field values
+    // of its xy-face (rm_accel.hip sdf_quads_kernel) -- TWO 16-byte loads per sample (this layer and the next)
+    // instead of eight scalar ones: the kernel is bound by the L1's tag lookups, one per lane and load for rays
+    // this incoherent.  Same values, same arithmetic as the row-major reads of the restatement.
+    const float4* __restrict__ g = reinterpret_cast<const float4*>(sc.sdf);
     const unsigned r00 = __umul24(__umul24((unsigned)iz, (unsigned)ry) + (unsigned)iy, (unsigned)rx) + (unsigned)ix;
-    const unsigned sy = (unsigned)rx, sz = __umul24((unsigned)ry, (unsigned)rx);
-    typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
-    const pair_t t00 = *reinterpret_cast<const pair_t*>(g + r00), t10 = *reinterpret_cast<const pair_t*>(g + (r00 + sy));
-    const pair_t t01 = *reinterpret_cast<const pair_t*>(g + (r00 + sz)), t11 = *reinterpret_cast<const pair_t*>(g + (r00 + sz + sy));
-    const float a00 = t00.x + (t00.y - t00.x) * fx;
-    const float a10 = t10.x + (t10.y - t10.x) * fx;
-    const float a01 = t01.x + (t01.y - t01.x) * fx;
-    const float a11 = t11.x + (t11.y - t11.x) * fx;
+    const float4 t0 = g[r00], t1 = g[r00 + __umul24((unsigned)ry, (unsigned)rx)];
+    const float a00 = t0.x + (t0.y - t0.x) * fx;
+    const float a10 = t0.z + (t0.w - t0.z) * fx;
+    const float a01 = t1.x + (t1.y - t1.x) * fx;
+    const float a11 = t1.z + (t1.w - t1.z) * fx;
     const float b0 = a00 + (a10 - a00) * fy;
     const float b1 = a01 + (a11 - a01) * fy;
     return b0 + (b1 - b0) * fz;
