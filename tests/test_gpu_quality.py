@@ -55,3 +55,5 @@ def test_sdf_api_errors(native):
             ctx.render_sdf_frame(opts, mc, 256)            # voxelRes mismatch
         with pytest.raises(Exception):
             ctx.set_sdf_volume(np.ones(8, np.float32), (1, 8, 1))
+        with pytest.raises(Exception):
+            ctx.set_sdf_volume(np.ones(4097 * 4, np.float32), (4097, 2, 2))   # more than 4096 cells on an axis
