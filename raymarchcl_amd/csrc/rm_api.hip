@@ -94,7 +94,9 @@ struct rm_ctx {
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
-  int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most
+  int pass_pack = 5;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most (16 passes
+                             // still go out as 4 pixels x 16; a run of 25 as ONE launch of 2 pixels x 32 slots instead of
+                             // 16 + 9: config 5 -2 %; 64 passes measured equal as 4 x 16, 2 x 32 or 1 x 64)
   int pack_waste = 60;       // RAYMARCH_PACK_WASTE: % of lane turns a partial last group may leave without a
                              // pass (their lanes still trace other lanes' secondary rays: 25 passes as
                              // 16 + 9 measured 12 % faster than as 6 x 4 + 1)
@@ -293,7 +295,7 @@ struct FrameOut {
 // The pipeline of core.clj:76-97 on resident inputs: accumulator from zero, `iter` passes in
 // order.  Consecutive passes whose records are identical apart from .time (what
 // core.clj:99-106 produces) and share a hit threshold go out pass-packed, as many per launch
-// of the frame kernel as one wavefront holds (16 by default: the whole frame of BASELINE's
+// of the frame kernel as one wavefront holds (up to 32 by default; 16 passes are ONE launch: the whole frame of BASELINE's
 // headline configuration is ONE launch); more passes, or a record that differs otherwise,
 // start a new launch, which continues from the accumulator the previous one left (launches
 // of a stream are ordered).
