@@ -211,8 +211,10 @@ int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, 
  * restatement of the same algorithm (oracle/rm_restate.c sdf_*), which is its only pin.
  *
  * rm_set_sdf_volume: rx*ry*rz float32, x fastest, copied to HBM (independent of the byte
- * volume).  rm_render_sdf_frame: as rm_render_frame; voxelRes of the records must equal
- * the field's size; isoVal is ignored. */
+ * volume); 2..4096 cells per axis, fewer than 2^32 cells.  The call also builds what the kernel
+ * samples -- one float4 per cell holding the four field values of the cell's xy-face, 4x the
+ * field's size -- once per field.  rm_render_sdf_frame: as rm_render_frame; voxelRes of the
+ * records must equal the field's size; isoVal is ignored. */
 int rm_set_sdf_volume(rm_ctx* ctx, const float* sdf, int rx, int ry, int rz);
 int rm_render_sdf_frame(rm_ctx* ctx, const void* opts544_array, const float* mc_array, int iter,
                         int n, float* pixels_out, uint32_t* argb_out);
