@@ -367,13 +367,21 @@ def main():
             for _ in range(5):
                 hctx.render_frame_into(opts, h_mc, n, h_px, h_argb)
             pinned_ms = (time.perf_counter() - th) / 5 * 1e3
+            # ... and only the ARGB image read back: what the reference's pipeline transfers (it reads q-buf, core.clj:91-97)
+            hctx.render_frame_into(opts, h_mc, n, None, h_argb)
+            th = time.perf_counter()
+            for _ in range(5):
+                hctx.render_frame_into(opts, h_mc, n, None, h_argb)
+            argb_only_ms = (time.perf_counter() - th) / 5 * 1e3
             hctx.close()
             out["host_boundary"] = {"ms_per_frame": round(host_ms, 3),
                                     "Mrays_per_s": round(samples_per_frame / host_ms / 1e3, 2),
                                     "ms_per_frame_pinned": round(pinned_ms, 3),
+                                    "ms_per_frame_pinned_argb_only": round(argb_only_ms, 3),
                                     "note": "rm_render_frame with host buffers (PCIe-inclusive: 4 MiB of tables up, "
                                             "18 MB of pixels back); _pinned: the caller's buffers registered with "
-                                            "rm_pin_host_buffer"}
+                                            "rm_pin_host_buffer; _argb_only: pinned, pixels_out = NULL -- only the 3.7 MB ARGB image comes back, "
+                                            "which is all the reference's pipeline reads (core.clj:91-97)"}
         if world == 1:
             # the other arithmetic contract, same frame, strictly serial (reported, never `value`)
             other = "cpu" if args.contract == "gfx950" else "gfx950"
