@@ -181,10 +181,12 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
     const bool oct = c->use_octants;
     const int tables = oct ? 9 : 1;
     // Row-major tables have the cheapest index arithmetic and win while the Infinity Cache
-    // catches most misses (bricks: +3 % at 256^3, equal at 512^3); far beyond it every miss
-    // goes to HBM and locality wins (1024^3: -6.6 %)
+    // catches most misses (bricks: +1..3 % at 256^3); beyond it misses go to HBM and locality wins: 1024^3
+    // -6.6 % (layout 1), 512^3 -2.5 % with the brick number formed by shifts (layout 3, round 4; with layout 1's
+    // multiplies and 64-bit offsets it had been a draw)
+    const bool cube512 = v.rx == 512 && v.ry == 512 && v.rz == 512 && c->pow2_tables;
     const bool bricked = oct &&
-                         (c->bricks >= 0 ? c->bricks == 1 : vox * 13 > ((size_t)4 << 30));
+                         (c->bricks >= 0 ? c->bricks == 1 : (vox * 13 > ((size_t)4 << 30) || cube512));
     const size_t tbytes = bricked ? (size_t)rmk::bricked_bytes(v.rx, v.ry, v.rz) : vox;
     hipEvent_t t0 = c->ev_b0, t1 = c->ev_b1;
     HIP_TRY(v.dist_buf.reserve(tbytes * tables));
@@ -216,7 +218,8 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   out->oct_stride = v.oct_stride;
   out->bricked = v.bricked;
   // cubic power-of-two grid whose tables stay below 4 GiB: shift-or cell index, 32-bit buffer offsets
-  if (!v.bricked && v.rx == v.ry && v.ry == v.rz && (v.rx & (v.rx - 1)) == 0 && v.rx >= 2 &&
+  // (bricked tables: only on the 512^3 grid with octants, walk_step LAYOUT 3 has that edge compiled in)
+  if ((!v.bricked || (v.rx == 512 && v.oct_stride)) && v.rx == v.ry && v.ry == v.rz && (v.rx & (v.rx - 1)) == 0 && v.rx >= 2 &&
       vox * (v.oct_stride ? 9 : 1) < ((size_t)1 << 32) && c->pow2_tables) {
     unsigned k = 0;
     while ((1 << k) < v.rx) k++;

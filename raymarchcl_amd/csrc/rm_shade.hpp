@@ -139,9 +139,14 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 //      shift-ors, the bounds test one compare of the or-ed coordinates, and the table is read
 //      through a buffer descriptor with a 32-bit offset (no 64-bit address arithmetic per
 //      fetch; out-of-range offsets read 0, so the fetch needs no guard)
+//   3  the bricks of layout 1 with the arithmetic of layout 2, on the 512^3 grid (nine tables = 1.2 GB: beyond the
+//      Infinity Cache, where the locality of bricks pays, and below the 4 GiB one buffer descriptor reaches):
+//      positions in cell units, one bounds compare, brick number and byte within the brick by shifts and ors with
+//      the grid edge as a compile-time constant (three scalar registers fewer), 32-bit buffer offset
+constexpr unsigned kLog2Res3 = 9;  // LAYOUT 3: the grid is 512^3
 struct WalkTab {
   const uint8_t* __restrict__ dist8;   // table 0; tables 1..8 follow at oct_stride
-  __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2: all nine tables as one buffer
+  __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2, 3: all nine tables as one buffer
   unsigned res, sh;                    // LAYOUT 2: edge of the grid = 1 << sh
   float fres;
 };
@@ -150,16 +155,23 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
                      int* cell_out, unsigned long long table_off) {
   int d, j;
   unsigned cell;
-  if (LAYOUT == 2) {
+  if (LAYOUT >= 2) {
     // (M::cell: the bare conversion instruction; scene_distance has applied M::walk_guard)
     // p and delta are in CELL units in this layout: the reference's p * res (renderer.cl:165) with res a
     // power of two is an exact scaling that commutes with the rounding of every add (an add whose result
     // is subnormal is exact either way), so scene_distance scales the first sample and the step once and
     // the walk's p is, bit for bit, 2^k times the reference's at every sample
     const int qx = M::cell(p.x), qy = M::cell(p.y), qz = M::cell(p.z);
-    const bool ok = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < tab.res) & (steps > 0);  // renderer.cl:219, :221
-    cell = ((((unsigned)qz << tab.sh) | (unsigned)qy) << tab.sh) | (unsigned)qx;
-    d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, cell + (unsigned)table_off, 0, 0);
+    const unsigned sh = LAYOUT == 3 ? kLog2Res3 : tab.sh, res = LAYOUT == 3 ? (1u << kLog2Res3) : tab.res;
+    const bool ok = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < res) & (steps > 0);  // renderer.cl:219, :221
+    cell = ((((unsigned)qz << sh) | (unsigned)qy) << sh) | (unsigned)qx;  // (surf32 stays row-major)
+    unsigned at = cell;
+    if (LAYOUT == 3) {  // 8x4x4-cell bricks of 128 bytes, x fastest inside and between bricks (rm_accel.hip tab_index)
+      const unsigned brick = (((((unsigned)qz >> 2) << (sh - 2u)) | ((unsigned)qy >> 2)) << (sh - 3u)) | ((unsigned)qx >> 3);
+      const unsigned within = (((((unsigned)qz & 3u) << 2) | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
+      at = (brick << 7) | within;
+    }
+    d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.rsrc, at + (unsigned)table_off, 0, 0);
     j = max((int)__builtin_fmaf((float)d, inv_s, c0), 1);
     *cell_out = (int)cell;
     // one decision per sample: hit / go on / end
@@ -252,7 +264,7 @@ struct Tracer {
     tab_.sh = s.log2res;
     tab_.res = 1u << s.log2res;
     tab_.fres = (float)(1u << s.log2res);
-    if (LAYOUT == 2) {
+    if (LAYOUT >= 2) {
       const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
       tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
     }
@@ -484,11 +496,12 @@ struct Tracer {
         M::walk_guard(p, delta, steps);  // (device contract: a NaN operand ends the walk where the library conversion would)
         // cells per sample along the fastest axis, padded: bounds how many samples
         // certainly stay inside the empty neighbourhood dist8 reports
-        if (LAYOUT == 2) {  // cell units (walk_step): exact, the grid edge is a power of two
-          p = p * tab_.fres;
-          delta = delta * tab_.fres;
+        const float fres = LAYOUT == 3 ? (float)(1u << kLog2Res3) : tab_.fres;
+        if (LAYOUT >= 2) {  // cell units (walk_step): exact, the grid edge is a power of two
+          p = p * fres;
+          delta = delta * fres;
         }
-        const float s = LAYOUT == 2 ? fmaxf(fmaxf(__builtin_fabsf(delta.x), __builtin_fabsf(delta.y)), __builtin_fabsf(delta.z))
+        const float s = LAYOUT >= 2 ? fmaxf(fmaxf(__builtin_fabsf(delta.x), __builtin_fabsf(delta.y)), __builtin_fabsf(delta.z))
                                     : fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
                                             __builtin_fabsf(delta.z) * frz);
         const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
@@ -511,7 +524,7 @@ struct Tracer {
         if (r == 1) {
           const uint32_t w = sc.surf[cell];
           nrm = surf_normal<M>(w, smooth);
-          if (LAYOUT == 2) p = p * (1.0f / tab_.fres);  // (exact: back to the reference's units)
+          if (LAYOUT >= 2) p = p * (1.0f / fres);  // (exact: back to the reference's units)
           const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
           const float d = length(rpos - hit) - o.voxelSize;
           if (d < rd) { rd = d; rc = band_of((int)(w & 0xffu)); }

@@ -25,6 +25,8 @@ def main():
                     help="cpu: kernels in the OpenCL-CPU-device contract against the CPU restatement; gfx950: kernels "
                          "in the device contract against the reference kernel built for gfx950 (strict build), on the GPU")
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all cases)")
+    ap.add_argument("--passes", default="1,2,4,3,8,16", help="pass counts the cases draw from (default: the list the "
+                    "earlier rounds' seeds were logged with; add 25,32 for runs that fill 32 pass slots per wavefront)")
     ap.add_argument("--only", type=int, default=-1, help="replay the random stream but render only this case")
     ap.add_argument("--dump", default="", help="with --only: save the case's inputs and both results to this .npz")
     args = ap.parse_args()
@@ -37,6 +39,7 @@ def main():
     from raymarchcl_amd import _native, generators as gen, materials, structs
 
     rng = np.random.default_rng(args.seed)
+    pass_counts = [int(v) for v in args.passes.split(",")]
     vols = [("gyroid", 64), ("terrain", 64), ("blobs", 64), ("gyroid-crop", (64, 40, 48)), ("gyroid", 32),
             ("gyroid", 128), ("gyroid", 256), ("terrain", 128)]
     sparse = gen.make_blob_volume(64, radius=(0.01, 0.03))
@@ -53,7 +56,7 @@ def main():
         kind, vres = vols[int(rng.integers(len(vols)))]
         vox = sparse if (kind == "blobs" and rng.random() < 0.5) else scenes.volume(kind, vres)
         vres3 = [vres] * 3 if isinstance(vres, int) else list(vres)
-        w, h, it = int(rng.integers(17, 64)), int(rng.integers(9, 48)), int(rng.choice([1, 2, 4, 3, 8, 16]))
+        w, h, it = int(rng.integers(17, 64)), int(rng.integers(9, 48)), int(rng.choice(pass_counts))
         inside = rng.random() < 0.25
         eye = (rng.uniform(-0.9, 0.9, 3) if inside else
                rm.compute_eyepos(rng.uniform(0, 360), rng.uniform(1.2, 3.5), rng.uniform(-0.9, 1.6)))
