@@ -219,8 +219,8 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   out->bricked = v.bricked;
   // cubic power-of-two grid whose tables stay below 4 GiB: shift-or cell index, 32-bit buffer offsets
   // (bricked tables: only on the 512^3 grid with octants, walk_step LAYOUT 3 has that edge compiled in)
-  if ((!v.bricked || (v.rx == 512 && v.oct_stride)) && v.rx == v.ry && v.ry == v.rz && (v.rx & (v.rx - 1)) == 0 && v.rx >= 2 &&
-      vox * (v.oct_stride ? 9 : 1) < ((size_t)1 << 32) && c->pow2_tables) {
+  if ((!v.bricked || ((v.rx == 512 || v.rx == 1024) && v.oct_stride)) && v.rx == v.ry && v.ry == v.rz && (v.rx & (v.rx - 1)) == 0 && v.rx >= 2 &&
+      (vox * (v.oct_stride ? 9 : 1) < ((size_t)1 << 32) || (v.bricked && v.rx == 1024)) && c->pow2_tables) {
     unsigned k = 0;
     while ((1 << k) < v.rx) k++;
     out->log2res = k;

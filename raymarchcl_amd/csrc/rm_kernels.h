@@ -18,7 +18,7 @@ struct Accel {  // nullptrs = not available: the kernels then run the plain fixe
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
   unsigned long long oct_stride = 0;
   bool bricked = false;             // dist / oct tables in 8x4x4-cell bricks of 128 B (oct_stride = bricked table bytes)
-  unsigned log2res = 0;             // > 0: cubic grid of edge 1 << log2res, tables below 4 GiB: row-major (walk_step LAYOUT 2) or the bricks of the 512^3 grid (LAYOUT 3)
+  unsigned log2res = 0;             // > 0: cubic grid of edge 1 << log2res, tables below 4 GiB: row-major (walk_step LAYOUT 2) or the bricks of the 512^3 grid (LAYOUT 3); 10 with bricks: the 1024^3 grid (LAYOUT 4)
 };
 // bytes of one byte table in the bricked layout
 long long bricked_bytes(int rx, int ry, int rz);

@@ -376,10 +376,11 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
                                                                     d_counters, accel.oct_stride, seed_cast_gpu,  \
                                                                     accel.log2res);                               \
   } while (0)
-  const int layout = accel.bricked ? (accel.log2res ? 3 : 1) : (accel.log2res ? 2 : 0);
+  const int layout = accel.bricked ? (accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1)) : (accel.log2res ? 2 : 0);
   if (d_counters) { RM_LAUNCH(true, false, false, 0); }
   else if (acc && layout == 1) { if (tile_major) RM_LAUNCH(false, true, true, 1); else RM_LAUNCH(false, false, true, 1); }
   else if (acc && layout == 3) { if (tile_major) RM_LAUNCH(false, true, true, 3); else RM_LAUNCH(false, false, true, 3); }
+  else if (acc && layout == 4) { if (tile_major) RM_LAUNCH(false, true, true, 4); else RM_LAUNCH(false, false, true, 4); }
   else if (acc && layout == 2) { if (tile_major) RM_LAUNCH(false, true, true, 2); else RM_LAUNCH(false, false, true, 2); }
   else if (tile_major && acc) { RM_LAUNCH(false, true, true, 0); }
   else if (tile_major) { RM_LAUNCH(false, true, false, 0); }
@@ -465,8 +466,10 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.log2res = f.accel.log2res;
   if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
     if (f.arith == 1) RM_FRAME(false, RM_SDF_MINW, true, 0, 1); else RM_FRAME(false, RM_SDF_MINW, true, 0, 0);
-  } else if (f.accel.dist && f.accel.surf && f.accel.bricked && f.accel.log2res) {
+  } else if (f.accel.dist && f.accel.surf && f.accel.bricked && f.accel.log2res == 9) {
     RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 3);
+  } else if (f.accel.dist && f.accel.surf && f.accel.bricked && f.accel.log2res == 10) {
+    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 4);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
     RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 1);
   } else if (f.accel.dist && f.accel.surf && f.accel.log2res) {

@@ -1,7 +1,6 @@
 mkdir -p gpurun_out/r4q
-(python -m pytest tests/ -q -m gpu -x 2>&1 | tail -4
-for w in c3 c2 c5; do echo -n "$w: "; python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*\|"frac": [0-9.]*' | head -3 | tr '\n' ' '; echo; done
-python -c "
-import bench, json
-" ) > gpurun_out/r4q/final_tests.txt 2>&1
-cat gpurun_out/r4q/final_tests.txt
+(for p in 1 0 1 0; do echo -n "c5 RAYMARCH_POW2=$p: "; RAYMARCH_POW2=$p python bench.py --workload c5 --steps 6 --warmup 2 --no-cpu-baseline --frames-in-flight 1 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*' | head -1; done
+echo -n "c5 cpu contract pow2 1/0: "; for p in 1 0; do RAYMARCH_POW2=$p python bench.py --workload c5 --contract cpu --steps 6 --warmup 2 --no-cpu-baseline --frames-in-flight 1 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*' | head -1 | tr '\n' ' '; done; echo
+python -m pytest tests/test_gpu_configs.py tests/test_gpu_device_contract.py -q -m gpu -k "c5" 2>&1 | tail -2
+) > gpurun_out/r4q/l4c5.txt 2>&1
+cat gpurun_out/r4q/l4c5.txt
