@@ -99,12 +99,23 @@ def test_pass_packed_lane_maps_whole_frames(native, oracle_mod, monkeypatch, pas
     assert np.array_equal(argb, want_argb)
 
 
+def _single_pass_kernel_equals_frame_kernel(ctx, opts, mc, n, w, row):
+    """The single-pass kernel (rm_render_image_range) of the volume's table layout against the frame kernel on a
+    one-pass frame, on a band of eight rows: the two kernels instantiate the same walk for the layout."""
+    one, _ = ctx.render_frame(opts[:544], mc[:1], n)
+    band = np.zeros(4 * n, np.float32)
+    id0, id1 = row * w, (row + 8) * w
+    ctx.render_image(np.ascontiguousarray(mc[0]), opts[:544], band, n=n, id0=id0, id1=id1)
+    assert _eq(band[4 * id0:4 * id1], one[4 * id0:4 * id1])
+
+
 def test_c3_512_blobs_1080p_16spp(native, oracle_mod):
     wl, vox, vres, opts, mc = _bench_inputs("c3")
     n, w = wl["w"] * wl["h"], wl["w"]
     with native.Context(0) as ctx:
         ctx.set_volume(vox, vres)
         px, argb = ctx.render_frame(opts, mc, n)
+        _single_pass_kernel_equals_frame_kernel(ctx, opts, mc, n, w, 536)  # (table layout 3: bricks of the 512^3 grid)
     ids = _sample_ids(n, w, 1500, 12, rows=(540,))
     _check_against_oracle(oracle_mod, vox, opts, mc, n, ids, px, argb)
 
@@ -147,6 +158,7 @@ def test_c5_1024_volume_1080p_25spp(native, oracle_mod):
     with native.Context(0) as ctx:
         ctx.set_volume(vox, vres)
         px, argb = ctx.render_frame(opts, mc, n)
+        _single_pass_kernel_equals_frame_kernel(ctx, opts, mc, n, w, 600)  # (table layout 4: bricks of the 1024^3 grid)
     ids = _sample_ids(n, w, 1000, 14, rows=(600,))
     _check_against_oracle(oracle_mod, vox, opts, mc, n, ids, px, argb)
 
