@@ -376,7 +376,7 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
                                                                     d_counters, accel.oct_stride, seed_cast_gpu,  \
                                                                     accel.log2res);                               \
   } while (0)
-  const int layout = accel.bricked ? (accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1)) : (accel.log2res ? 2 : 0);
+  const int layout = accel.bricked ? (accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1)) : (accel.log2res ? 2 : 0);  // (layout 5: frame kernel only)
   if (d_counters) { RM_LAUNCH(true, false, false, 0); }
   else if (acc && layout == 1) { if (tile_major) RM_LAUNCH(false, true, true, 1); else RM_LAUNCH(false, false, true, 1); }
   else if (acc && layout == 3) { if (tile_major) RM_LAUNCH(false, true, true, 3); else RM_LAUNCH(false, false, true, 3); }
@@ -472,6 +472,8 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
     RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 4);
   } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
     RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 1);
+  } else if (f.accel.dist && f.accel.surf && f.accel.log2res == 8 && f.accel.oct_stride) {
+    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 5);
   } else if (f.accel.dist && f.accel.surf && f.accel.log2res) {
     RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 2);
   } else if (f.accel.dist && f.accel.surf) {

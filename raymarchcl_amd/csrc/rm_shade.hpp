@@ -143,11 +143,18 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 //      Infinity Cache, where the locality of bricks pays, and below the 4 GiB one buffer descriptor reaches):
 //      positions in cell units, one bounds compare, brick number and byte within the brick by shifts and ors with
 //      the grid edge as a compile-time constant (three scalar registers fewer), 32-bit buffer offset
+//   5  layout 2 for the 256^3 grid with the edge compiled in (shift counts, bound and scale as immediates: the
+//      allocator keeps 36 instead of 42 values in scratch)
 //   4  the same for the 1024^3 grid: its nine tables are 9 GiB, beyond any buffer descriptor (the hardware forms
 //      index * stride in 32 bits), so the byte is fetched by a plain 64-bit address = table number << 30 | brick
 //      offset, guarded by the bounds compare
 constexpr unsigned kLog2Res3 = 9;  // LAYOUT 3: the grid is 512^3
 constexpr unsigned kLog2Res4 = 10; // LAYOUT 4: the grid is 1024^3 (the same bricks behind 64-bit addresses: 9 GiB of tables)
+constexpr unsigned kLog2Res5 = 8;  // LAYOUT 5: layout 2 on the 256^3 grid, edge compiled in
+// grid edge (log2) that a layout has compiled in; 0 = read from the table descriptor at run time
+constexpr unsigned fixed_log2(int layout) {
+  return layout == 3 ? kLog2Res3 : (layout == 4 ? kLog2Res4 : (layout == 5 ? kLog2Res5 : 0u));
+}
 struct WalkTab {
   const uint8_t* __restrict__ dist8;   // table 0; tables 1..8 follow at oct_stride
   __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2, 3: all nine tables as one buffer
@@ -166,11 +173,11 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
     // is subnormal is exact either way), so scene_distance scales the first sample and the step once and
     // the walk's p is, bit for bit, 2^k times the reference's at every sample
     const int qx = M::cell(p.x), qy = M::cell(p.y), qz = M::cell(p.z);
-    const unsigned sh = LAYOUT == 3 ? kLog2Res3 : (LAYOUT == 4 ? kLog2Res4 : tab.sh), res = LAYOUT >= 3 ? (1u << sh) : tab.res;
+    const unsigned sh = fixed_log2(LAYOUT) ? fixed_log2(LAYOUT) : tab.sh, res = fixed_log2(LAYOUT) ? (1u << fixed_log2(LAYOUT)) : tab.res;
     const bool ok = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < res) & (steps > 0);  // renderer.cl:219, :221
     cell = ((((unsigned)qz << sh) | (unsigned)qy) << sh) | (unsigned)qx;  // (surf32 stays row-major)
     unsigned at = cell;
-    if (LAYOUT >= 3) {  // 8x4x4-cell bricks of 128 bytes, x fastest inside and between bricks (rm_accel.hip tab_index)
+    if (LAYOUT == 3 || LAYOUT == 4) {  // 8x4x4-cell bricks of 128 bytes, x fastest inside and between bricks (rm_accel.hip tab_index)
       const unsigned brick = (((((unsigned)qz >> 2) << (sh - 2u)) | ((unsigned)qy >> 2)) << (sh - 3u)) | ((unsigned)qx >> 3);
       const unsigned within = (((((unsigned)qz & 3u) << 2) | ((unsigned)qy & 3u)) << 3) | ((unsigned)qx & 7u);
       at = (brick << 7) | within;
@@ -271,7 +278,7 @@ struct Tracer {
     tab_.sh = s.log2res;
     tab_.res = 1u << s.log2res;
     tab_.fres = (float)(1u << s.log2res);
-    if (LAYOUT == 2 || LAYOUT == 3) {
+    if (LAYOUT == 2 || LAYOUT == 3 || LAYOUT == 5) {
       const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
       tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
     }
@@ -503,7 +510,7 @@ struct Tracer {
         M::walk_guard(p, delta, steps);  // (device contract: a NaN operand ends the walk where the library conversion would)
         // cells per sample along the fastest axis, padded: bounds how many samples
         // certainly stay inside the empty neighbourhood dist8 reports
-        const float fres = LAYOUT == 3 ? (float)(1u << kLog2Res3) : (LAYOUT == 4 ? (float)(1u << kLog2Res4) : tab_.fres);
+        const float fres = fixed_log2(LAYOUT) ? (float)(1u << fixed_log2(LAYOUT)) : tab_.fres;
         if (LAYOUT >= 2) {  // cell units (walk_step): exact, the grid edge is a power of two
           p = p * fres;
           delta = delta * fres;

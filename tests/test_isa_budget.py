@@ -15,9 +15,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-# the bench instantiations: accelerated, 7 waves/SIMD, table layout 2 (cubic power-of-two
-# grid), arithmetic contract gfx950 (bench default) and cpu
-KEYS = ["render_frame_kernelILb1ELi7ELb0ELi2ELi2E", "render_frame_kernelILb1ELi7ELb0ELi2ELi0E"]
+# the bench instantiations: accelerated, 7 waves/SIMD, table layout 5 (row-major tables of the 256^3
+# grid, edge compiled in), arithmetic contract gfx950 (bench default) and cpu -- and layout 2, the same
+# with the edge read at run time (other cubic power-of-two grids)
+KEYS = ["render_frame_kernelILb1ELi7ELb0ELi5ELi2E", "render_frame_kernelILb1ELi7ELb0ELi5ELi0E",
+        "render_frame_kernelILb1ELi7ELb0ELi2ELi2E", "render_frame_kernelILb1ELi7ELb0ELi2ELi0E"]
 KEY = KEYS[0]
 
 

@@ -16,8 +16,8 @@ python $R/tools/rocprof_summary.py $DB > $OUT/kernel_stats.txt 2>&1
 cd $R
 tools/pmc_run.sh final/pmc --steps 8 --warmup 2 --frames-in-flight 1 > $OUT/pmc_run.log 2>&1
 python tools/pmc_summary.py $OUT/pmc/p1/pmc_results.db $OUT/pmc/p2/pmc_results.db $OUT/pmc/p3/pmc_results.db \
-  $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 2, 2>" > $OUT/pmc.txt 2>&1
-python tools/pmc_summary.py $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 2, 2>" \
+  $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 5, 2>" > $OUT/pmc.txt 2>&1
+python tools/pmc_summary.py $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 5, 2>" \
   --traffic-json $OUT/pmc_traffic.json > $OUT/traffic.log 2>&1
 python - <<'PY'
 import json, os, sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Loop tree of one kernel in hipcc's gfx950 assembly with instruction counts per loop body.
 
-    python tools/isa_loops.py file.s 'render_frame_kernel<true, 7, false, 2, 2>' [--blocks]
+    python tools/isa_loops.py file.s 'render_frame_kernel<true, 7, false, 5, 2>' [--blocks]
 
 Per loop (LLVM's "Loop Header: Depth=" comments): VALU / SALU / VMEM / LDS / SMEM instructions of the
 blocks that belong to the loop itself (excl) and including its sub-loops (incl), scratch traffic.
