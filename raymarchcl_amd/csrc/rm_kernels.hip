@@ -23,6 +23,10 @@
 
 
 
+#ifndef RM_SDF_WAVE
+#define RM_SDF_WAVE 1  // quality mode: AO probes and soft-shadow marches of a wavefront's hits traced by all its lanes
+#endif
+
 namespace {
 
 constexpr int kTile = 8;            // tile edge in pixels; 64 px == one wavefront
@@ -198,7 +202,10 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
-    if (ACCEL) col = tr.shade_wave(id, wave_lds, live);
+    // secondary rays shared by the wavefront (quality mode: while the record's AO probes fit the exchange area --
+    // uniform; the accelerated kernels get frames with more probes through the single-pass kernels, rm_api.hip)
+    const bool shared = ACCEL || (SDFM && RM_SDF_WAVE && opts->aoIter + 1 <= Tr::kWaveLdsRes);
+    if (shared) col = tr.shade_wave(id, wave_lds, live);
     else if (live) col = tr.shade(id);
     // mix(p, col, frameBlend) in pass order: renderer.cl:492
     if (pp > 1) {
@@ -230,7 +237,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
 template <bool ACCEL, int MINW, bool SDFM, int LAYOUT = 0, int ARITH = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
   static_assert(kWavesPerBlock == 1, "the LDS area below belongs to one wavefront");
-  __shared__ float wave_lds[ACCEL ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
+  __shared__ float wave_lds[(ACCEL || (SDFM && RM_SDF_WAVE)) ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
   frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
 }
 

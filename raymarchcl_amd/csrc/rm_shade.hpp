@@ -1043,9 +1043,13 @@ struct Tracer {
         if (att > o.minLightAtt) {
           const v3 ldir = normalize(dlv);
           const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
-          Hit h{};
-          march(muladd(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
-          lds_res(light, owner) = h.distance;
+          if (SDFM) {  // quality mode: the penumbra estimate itself is the task's result
+            lds_res(light, owner) = soft_shadow_sdf(muladd(ldir, o.shadowBias, opos), ldir, lmax);
+          } else {
+            Hit h{};
+            march(muladd(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
+            lds_res(light, owner) = h.distance;
+          }
         }
       }
     }
@@ -1111,7 +1115,7 @@ struct Tracer {
         if (att > o.minLightAtt) {
           const v3 ldir = normalize(dl);
           const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
-          const float sh = M::step(lmax, lds_res(i, lane));
+          const float sh = SDFM ? lds_res(i, lane) : M::step(lmax, lds_res(i, lane));
           if (sh > 0.0f) {
             const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
             diff = diff + inc * M::fmax(0.0f, dot(ldir, normal));

@@ -26,6 +26,7 @@ def _records(w, h, it, vres, mat, theta, over=None):
     ("torus", (64, 40, 56), "orange-stripes", 30, dict(lightScatter=0.05)),
     ("gyroid", (64, 64, 64), "metal2", 120, None),
     ("torus", (32, 32, 32), "ao", 200, dict(aoIter=3, shadowIter=40)),
+    ("torus", (32, 32, 32), "ao", 200, dict(aoIter=9, shadowIter=40)),   # more probes than the exchange area holds: per-lane path
 ])
 def test_sdf_frame_matches_its_restatement(native, oracle_mod, kind, vres, mat, theta, over):
     w, h, it = 56, 40, 2
