@@ -246,7 +246,7 @@ int rm_frame_device_argb(rm_ctx* ctx, const void* d_opts, const float* d_mc, int
  * ARGB image (the reference's q-buf, core.clj:91-97).  Asynchronous on the context's stream. */
 int rm_resolve_device_argb(rm_ctx* ctx, const uint32_t* d_argb_tiles_all, int parts, int n, int width,
                            uint32_t* d_argb);
-/* The unpartitioned frame in ONE kernel launch per 32 passes at most (one for a 16-pass frame): all passes, blended in order, the row-major
+/* The unpartitioned frame in ONE kernel launch per group of 16 passes (one for a 16-pass frame; a run of 20-31 passes is one launch too): all passes, blended in order, the row-major
  * float4 image into d_pixels (nullable) and TonemapImage(d_opts[0]) into d_argb (nullable;
  * at least one of the two).  Same validation contract as rm_frame_device.
  * On a multi-device context (rm_create_multi) the frame is tiled over its devices; the records and

@@ -471,7 +471,7 @@ class Context:
         check(lib().rm_resolve_device_argb(self._h, d_argb_tiles_all, parts, n, width, d_argb))
 
     def frame_device_full(self, d_opts, d_mc, iters, n, width, d_pixels=None, d_argb=None):
-        """The unpartitioned frame, one launch per group of up to 32 passes (16 passes: one launch): row-major pixels and / or ARGB; asynchronous."""
+        """The unpartitioned frame, one launch per group of 16 passes (a run of 20-31 passes: one launch): row-major pixels and / or ARGB; asynchronous."""
         check(lib().rm_frame_device_full(self._h, d_opts, d_mc, iters, n, width, d_pixels, d_argb))
 
     def last_frame_breakdown(self):

@@ -94,9 +94,11 @@ struct rm_ctx {
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
-  int pass_pack = 5;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most (16 passes
-                             // still go out as 4 pixels x 16; a run of 25 as ONE launch of 2 pixels x 32 slots instead of
-                             // 16 + 9: config 5 -2 %; 64 passes measured equal as 4 x 16, 2 x 32 or 1 x 64)
+  int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most.  Default 4 =
+                             // 4 pixels x 16 passes, measured best for full groups (64 passes as 4 x 16 / 2 x 32 / 1 x 64:
+                             // 136.0 / 137.3 / 140.3 ms) ...
+  bool pass_pack_auto = true;  // ... except that a run of 20..31 passes goes out as ONE launch of 2 pixels x 32 slots instead of
+                             // 16 + a partial group (25 passes: config 5 -2.7 %); off when RAYMARCH_PASS_PACK is given
   int pack_waste = 60;       // RAYMARCH_PACK_WASTE: % of lane turns a partial last group may leave without a
                              // pass (their lanes still trace other lanes' secondary rays: 25 passes as
                              // 16 + 9 measured 12 % faster than as 6 x 4 + 1)
@@ -298,7 +300,7 @@ struct FrameOut {
 // The pipeline of core.clj:76-97 on resident inputs: accumulator from zero, `iter` passes in
 // order.  Consecutive passes whose records are identical apart from .time (what
 // core.clj:99-106 produces) and share a hit threshold go out pass-packed, as many per launch
-// of the frame kernel as one wavefront holds (up to 32 by default; 16 passes are ONE launch: the whole frame of BASELINE's
+// of the frame kernel as one wavefront holds (16, or 32 slots for a run of 20..31; 16 passes are ONE launch: the whole frame of BASELINE's
 // headline configuration is ONE launch); more passes, or a record that differs otherwise,
 // start a new launch, which continues from the accumulator the previous one left (launches
 // of a stream are ordered).
@@ -312,7 +314,10 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     if (run_end <= i0) {  // a new run of records that differ in .time only: its pass packing
       run_end = i1;
       while (run_end < iter && same_as_prev[run_end]) run_end++;
-      pp_log2 = rmk::choose_pass_pack(run_end - i0, c->pass_pack, c->pack_waste);
+      const int run = run_end - i0;
+      // (the same waste rule as choose_pass_pack: 32 slots only if at most pack_waste % of them stay without a pass)
+      const bool one_of_32 = c->pass_pack_auto && run > 16 && run < 32 && 32.0 * 100.0 <= (100.0 + c->pack_waste) * run;
+      pp_log2 = one_of_32 ? 5 : rmk::choose_pass_pack(run, c->pass_pack, c->pack_waste);
     }
     i1 = std::min(run_end, i0 + (1 << pp_log2));  // one launch = what one wavefront holds
     const size_t acc_bytes = out.row_major ? (size_t)n * 16
@@ -445,7 +450,7 @@ static int create_one(int device_id, rm_ctx** out) {
   const char* xr = getenv("RAYMARCH_XCD_ROWS");
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* pk = getenv("RAYMARCH_PASS_PACK");
-  if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) c->pass_pack = atoi(pk);
+  if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) { c->pass_pack = atoi(pk); c->pass_pack_auto = false; }
   const char* bk = getenv("RAYMARCH_BRICKS");
   if (bk && (bk[0] == '0' || bk[0] == '1')) c->bricks = bk[0] - '0';
   const char* pw = getenv("RAYMARCH_PACK_WASTE");
