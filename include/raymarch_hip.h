@@ -123,7 +123,9 @@ int rm_set_seed_cast(rm_ctx* ctx, int mode);
  * caller follow the context's contract, while the ARGB words rm_render_sdf_frame itself returns
  * are tonemapped with the CPU-device arithmetic. */
 #define RM_CONTRACT_CPU_DEVICE 0
-#define RM_CONTRACT_GFX950 1
+#define RM_CONTRACT_GFX950_STRICT 1
+#define RM_CONTRACT_GFX950 RM_CONTRACT_GFX950_STRICT /* name of ABI 3 */
+#define RM_CONTRACT_GFX950_DEFAULT 2
 int rm_set_contract(rm_ctx* ctx, int contract);
 
 /* v-buf: vio/load-volume wraps the bytes into a read-only buffer that the

@@ -60,6 +60,10 @@ EXPORTS = [
 ]
 
 
+# rm_set_contract names (include/raymarch_hip.h): whose arithmetic the kernels reproduce
+CONTRACTS = {"cpu": 0, "gfx950": 1, "gfx950-strict": 1, "gfx950-default": 2}
+
+
 class RmError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libraymarch_hip: {msg} (code {code})")
@@ -381,7 +385,7 @@ class Context:
         this GPU with -ffp-contract=off and correctly rounded divide/sqrt (checked bit for bit against
         that build); "cpu": the results of an OpenCL CPU device on x86-64 (checked against the CPU
         oracle) -- include/raymarch_hip.h rm_set_contract."""
-        check(lib().rm_set_contract(self._h, {"cpu": 0, "gfx950": 1}[contract]))
+        check(lib().rm_set_contract(self._h, CONTRACTS[contract]))
 
     def set_seed_cast(self, mode):
         """"x86" (default): the undefined (uint) casts of the seed expressions as an OpenCL CPU

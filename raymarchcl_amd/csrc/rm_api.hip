@@ -106,7 +106,7 @@ struct rm_ctx {
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
-  int contract = RM_CONTRACT_GFX950;  // rm_set_contract: RM_CONTRACT_GFX950 (default) / RM_CONTRACT_CPU_DEVICE
+  int contract = RM_CONTRACT_GFX950_STRICT;  // rm_set_contract: RM_CONTRACT_GFX950_STRICT / RM_CONTRACT_GFX950_DEFAULT / RM_CONTRACT_CPU_DEVICE
   // records validated by rm_check_device_opts
   std::vector<RmOpts> dev_recs;
   std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
@@ -128,6 +128,14 @@ struct rm_ctx {
   std::vector<rm_ctx*> peers;
   rm_ctx* parent = nullptr;
 };
+
+// The context's arithmetic contract as the kernels are instantiated on it (rmk::ArithOf, rm_math.hpp) -- the ONE place
+// that maps rm_set_contract / rm_set_seed_cast to a kernel family.  sdf: the quality mode has CPU-device arithmetic only.
+static int contract_arith(const rm_ctx* c, bool sdf = false) {
+  if (!sdf && c->contract == RM_CONTRACT_GFX950_DEFAULT) return 3;
+  if (!sdf && c->contract == RM_CONTRACT_GFX950_STRICT) return 2;
+  return c->seed_cast ? 1 : 0;
+}
 
 namespace {
 
@@ -274,7 +282,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
                                   static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt, c->seed_cast,
-                                  c->contract == RM_CONTRACT_GFX950));
+                                  contract_arith(c)));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
   rm_counters got{};
   if (counters)
@@ -332,11 +340,11 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       if (i0 == 0) HIP_TRY(hipMemsetAsync(out.acc, 0, acc_bytes, c->stream));
       HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0,
                                       resx, out.acc, n, 0, n, out.tile_first, out.tile_stride, !out.row_major, nullptr,
-                                      c->seed_cast, c->contract == RM_CONTRACT_GFX950));
+                                      c->seed_cast, contract_arith(c)));
       launches++;
       i0 = i0 + 1;
       if (i0 == iter && out.argb && out.row_major)
-        HIP_TRY(rmk::launch_tonemap(c->stream, out.acc, d_opts, out.argb, n, c->contract == RM_CONTRACT_GFX950));
+        HIP_TRY(rmk::launch_tonemap(c->stream, out.acc, d_opts, out.argb, n, contract_arith(c)));
       continue;
     }
     rmk::FrameLaunch f;
@@ -358,7 +366,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.xcd_rows = c->xcd_rows;
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
-    f.arith = (c->contract == RM_CONTRACT_GFX950 && !sdf_frame) ? 2 : (c->seed_cast ? 1 : 0);
+    f.arith = contract_arith(c, sdf_frame);
     HIP_TRY(rmk::launch_render_frame(c->stream, f));
     launches++;
     i0 = i1;
@@ -367,7 +375,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
   if (out.argb && !out.row_major)
     HIP_TRY(rmk::launch_tonemap(c->stream, out.acc, d_opts, out.argb,
                                 rmk::tiles_per_part(rmk::tiles_total(resx, n), out.tile_stride) * 64,
-                                c->contract == RM_CONTRACT_GFX950 && !sdf_frame));
+                                contract_arith(c, sdf_frame)));
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->timed = true;
   c->launches = launches;
@@ -546,7 +554,7 @@ int rm_set_seed_cast(rm_ctx* c, int mode) {
 
 int rm_set_contract(rm_ctx* c, int contract) {
   if (!c) return fail(RM_EINVAL, "rm_ctx is NULL");
-  if (contract != RM_CONTRACT_CPU_DEVICE && contract != RM_CONTRACT_GFX950)
+  if (contract != RM_CONTRACT_CPU_DEVICE && contract != RM_CONTRACT_GFX950_STRICT && contract != RM_CONTRACT_GFX950_DEFAULT)
     return fail(RM_EINVAL, "unknown arithmetic contract %d", contract);
   c->contract = contract;
   for (rm_ctx* p : c->peers) p->contract = contract;
@@ -829,7 +837,7 @@ int rm_tonemap_image(rm_ctx* c, const float* pixels, const void* opts544, uint32
   HIP_TRY(hipMemcpyAsync(c->pix_buf.p, pixels, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(rmk::launch_tonemap(c->stream, static_cast<const float*>(c->pix_buf.p),
                               static_cast<const RmOpts*>(c->opts_buf.p),
-                              static_cast<uint32_t*>(c->argb_buf.p), n, c->contract == RM_CONTRACT_GFX950));
+                              static_cast<uint32_t*>(c->argb_buf.p), n, contract_arith(c)));
   HIP_TRY(hipMemcpyAsync(argb, c->argb_buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
@@ -913,7 +921,7 @@ static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc
     HIP_TRY(rmk::launch_resolve_argb(c->stream, static_cast<const uint32_t*>(c->atile_buf.p), world, tpp, resx, d_argb, n));
   else
     HIP_TRY(rmk::launch_resolve(c->stream, static_cast<const float*>(c->tile_buf.p), world, tpp, d_opts, d_pixels,
-                                d_argb, n, c->contract == RM_CONTRACT_GFX950 && !sdf));
+                                d_argb, n, contract_arith(c, sdf)));
   HIP_TRY(hipEventRecord(c->ev_resolved, c->stream));
   c->resolved_once = true;
   return RM_OK;
@@ -1158,7 +1166,7 @@ int rm_resolve_device(rm_ctx* c, const float* d_tiles_all, int parts, const void
   if (parts < 1 || n <= 0 || width <= 0) return fail(RM_EINVAL, "parts = %d, n = %d, width = %d", parts, n, width);
   const int tpp = rmk::tiles_per_part(rmk::tiles_total(width, n), parts);
   HIP_TRY(rmk::launch_resolve(c->stream, d_tiles_all, parts, tpp, static_cast<const RmOpts*>(d_opts),
-                              d_pixels, d_argb, n, c->contract == RM_CONTRACT_GFX950));
+                              d_pixels, d_argb, n, contract_arith(c)));
   return RM_OK;
 }
 

@@ -27,7 +27,7 @@ hipError_t launch_unbrick(hipStream_t st, const uint8_t* d_bricked, int rx, int 
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters, int seed_cast_gpu = 0, bool device_arith = false);
+                              Counters* d_counters, int seed_cast_gpu = 0, int arith = 0);
 // One launch of the frame kernel (rm_kernels.hip render_frame_kernel): `passes` consecutive
 // RenderImage passes (at most 2^pp_log2: what one wavefront holds) over partition (tile_first, tile_stride)
 // of the image, blended in order into `acc`.  pp_log2 > 0: a wavefront holds 2^pp_log2 passes of
@@ -44,8 +44,9 @@ struct FrameLaunch {
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
-  // arithmetic contract (rm_math.hpp): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
-  // the seed casts (rm_set_seed_cast), 2 = ROCm's OpenCL library on this GPU (rm_set_contract)
+  // arithmetic contract (rm_math.hpp ArithOf): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
+  // the seed casts (rm_set_seed_cast), 2 / 3 = ROCm's OpenCL library on this GPU as the strict / default
+  // build of the reference uses it (rm_set_contract).  Every launcher below takes the same number.
   int arith = 0;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
@@ -54,11 +55,11 @@ int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)
 hipError_t launch_resolve(hipStream_t st, const float* d_tiles, int parts, int tiles_per_part,
                           const RmOpts* d_opts0, float* d_pixels, uint32_t* d_argb, int n,
-                          bool device_arith = false);
+                          int arith = 0);
 hipError_t launch_resolve_argb(hipStream_t st, const uint32_t* d_argb_tiles, int parts, int tiles_per_part, int resx,
                                uint32_t* d_argb, int n);
 hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d_opts,
-                          uint32_t* d_argb, int n, bool device_arith = false);
+                          uint32_t* d_argb, int n, int arith = 0);
 // surf32 of a resident volume for hit threshold `iso` (rm_accel.hip) and -- when d_dist is not
 // null -- dist8 alone by separable passes (d_tmp: scratch of the volume's size)
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,

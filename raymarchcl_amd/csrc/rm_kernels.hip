@@ -59,9 +59,9 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
 // contiguous 1 KiB store per wave) instead of at the work-item id; used by the
 // device-resident pipeline and the multi-GPU partition, un-permuted by
 // resolve_kernel.
-// DEVICE: the arithmetic contract -- false: OpenCL CPU device (seed-cast lowering chosen at run
-// time), true: ROCm's OpenCL library on this GPU (rm_math.hpp)
-template <bool COUNT, bool TILE_MAJOR, bool ACCEL, int LAYOUT = 0, bool DEVICE = false>
+// ARITH: the arithmetic contract (rmk::ArithOf, rm_math.hpp) -- 4: OpenCL CPU device (seed-cast lowering chosen at
+// run time), 2 / 3: ROCm's OpenCL library on this GPU, strict / default build of the reference
+template <bool COUNT, bool TILE_MAJOR, bool ACCEL, int LAYOUT = 0, int ARITH = 4>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   rmk::Scene sc{vox, mc, opts, dist8, surf32, oct_stride};
   sc.seed_cast_gpu = seed_cast_gpu;
   sc.log2res = log2res;
-  using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<2>>::type;
+  using M = typename rmk::ArithOf<ARITH>::type;
   rmk::Tracer<COUNT, ACCEL, false, LAYOUT, M> tr(sc);
   if (id >= 0) {
     const rmk::v3 col = tr.shade(id);
@@ -138,7 +138,7 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
   const float c[3] = {px, py, pz};
   uint32_t ch[3];
   for (int k = 0; k < 3; k++) {
-    const float t = c[k] / (g + c[k]);
+    const float t = M::div(c[k], g + c[k]);  // renderer.cl:453
     const float v = t * t * 255.0f;
     ch[k] = (uint32_t)M::to_int(M::clamp(v, 0.0f, 255.0f));
   }
@@ -148,11 +148,11 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 // A launch holds at most the passes ONE wavefront holds (2^pp_log2): frames with more passes go out as several
 // launches that continue each other's accumulator (rm_api.hip frame_on_device) -- nothing of a sample then lives
 // across the body of another, and the kernel has no loop over groups of passes.
-// ARITH: 0 = OpenCL CPU device arithmetic and casts, 1 = the same with the GPU lowering of the seed
-// casts, 2 = ROCm's OpenCL library on this GPU (rm_math.hpp)
+// ARITH: the arithmetic contract, rmk::ArithOf (rm_math.hpp): 0 = OpenCL CPU device arithmetic and casts, 1 = the same
+// with the GPU lowering of the seed casts, 2 / 3 = ROCm's OpenCL library on this GPU, strict / default reference build
 template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH>
 __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
-  using M = typename std::conditional<ARITH == 2, rmk::MathOcl, rmk::MathX86<(ARITH == 1 ? 1 : 0)>>::type;
+  using M = typename rmk::ArithOf<ARITH>::type;
   using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
   const int pp_log2 = a.pp_log2;
   const int pp = 1 << pp_log2;              // passes per wavefront
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
 }
 
-template <bool DEVICE>
+template <int ARITH>
 __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ pixels,
                                                       const RmOpts* __restrict__ opts,
                                                       uint32_t* __restrict__ argb, int n) {
@@ -249,15 +249,14 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
   for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n;
        id += (long long)gridDim.x * blockDim.x) {
     const float4 p = pixels[id];
-    using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<0>>::type;
-    argb[id] = tonemap_argb<M>(p.x, p.y, p.z, g);
+    argb[id] = tonemap_argb<typename rmk::ArithOf<ARITH>::type>(p.x, p.y, p.z, g);
   }
 }
 
 // Tile-major accumulators of `parts` interleaved partitions (partition r owns
 // tiles r, r+parts, ...; each partition's buffer holds tiles_per_part tiles of
 // 64 float4) -> row-major float4 pixels and/or tonemapped ARGB.
-template <bool DEVICE>
+template <int ARITH>
 __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__ tiles, int parts,
                                                       int tiles_per_part,
                                                       const RmOpts* __restrict__ opts,
@@ -274,8 +273,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4* __restrict__
     const long long at = ((long long)(tile % parts) * tiles_per_part + tile / parts) * 64 + lane;
     const float4 p = tiles[at];
     if (pixels) pixels[id] = p;
-    using M = typename std::conditional<DEVICE, rmk::MathOcl, rmk::MathX86<0>>::type;
-    if (argb) argb[id] = tonemap_argb<M>(p.x, p.y, p.z, g);
+    if (argb) argb[id] = tonemap_argb<typename rmk::ArithOf<ARITH>::type>(p.x, p.y, p.z, g);
   }
 }
 
@@ -356,10 +354,41 @@ hipError_t launch_filter_check(hipStream_t st, const float* rays, const RmOpts* 
 
 int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
+// ---- run-time -> compile-time: ONE switch per template axis, used by every launcher ----
+template <int V> using ic = std::integral_constant<int, V>;
+// the contract of a context (rm_api.hip contract_arith) -> ArithOf index; `cpu` = what 0 / 1 mean for the launcher
+// (the frame kernel is instantiated per seed-cast lowering, the single-pass kernels take it at run time)
+template <class F>
+void with_arith(int arith, bool runtime_cast, F&& fn) {
+  switch (arith) {
+    case 3: fn(ic<3>{}); break;
+    case 2: fn(ic<2>{}); break;
+    case 1: if (runtime_cast) fn(ic<4>{}); else fn(ic<1>{}); break;
+    default: if (runtime_cast) fn(ic<4>{}); else fn(ic<0>{}); break;
+  }
+}
+template <class F>
+void with_layout(int layout, F&& fn) {
+  switch (layout) {
+    case 1: fn(ic<1>{}); break;
+    case 2: fn(ic<2>{}); break;
+    case 3: fn(ic<3>{}); break;
+    case 4: fn(ic<4>{}); break;
+    case 5: fn(ic<5>{}); break;
+    default: fn(ic<0>{}); break;
+  }
+}
+// table layout of a volume's derived structures (walk_step); `frame`: layout 5 exists in the frame kernel only
+int layout_of(const rmk::Accel& accel, bool frame) {
+  if (accel.bricked) return accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1);
+  if (frame && accel.log2res == 8 && accel.oct_stride) return 5;
+  return accel.log2res ? 2 : 0;
+}
+
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters, int seed_cast_gpu, bool device_arith) {
+                              Counters* d_counters, int seed_cast_gpu, int arith) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const long long my_tiles =
@@ -369,31 +398,22 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   const float4* mc4 = reinterpret_cast<const float4*>(mc);
   float4* px4 = reinterpret_cast<float4*>(pixels);
   const dim3 grid(blocks), block(64 * kWavesPerBlock);
-  const bool acc = accel.dist && accel.surf;
-#define RM_LAUNCH(C, T, A, B)                                                                                     \
-  do {                                                                                                            \
-    if (device_arith)                                                                                             \
-      render_pass_kernel<C, T, A, B, true><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, px4, \
-                                                                   n, id0, id1, tile_first, tile_stride,          \
-                                                                   d_counters, accel.oct_stride, seed_cast_gpu,   \
-                                                                   accel.log2res);                                \
-    else                                                                                                          \
-      render_pass_kernel<C, T, A, B, false><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts,     \
-                                                                    px4, n, id0, id1, tile_first, tile_stride,    \
-                                                                    d_counters, accel.oct_stride, seed_cast_gpu,  \
-                                                                    accel.log2res);                               \
-  } while (0)
-  const int layout = accel.bricked ? (accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1)) : (accel.log2res ? 2 : 0);  // (layout 5: frame kernel only)
-  if (d_counters) { RM_LAUNCH(true, false, false, 0); }
-  else if (acc && layout == 1) { if (tile_major) RM_LAUNCH(false, true, true, 1); else RM_LAUNCH(false, false, true, 1); }
-  else if (acc && layout == 3) { if (tile_major) RM_LAUNCH(false, true, true, 3); else RM_LAUNCH(false, false, true, 3); }
-  else if (acc && layout == 4) { if (tile_major) RM_LAUNCH(false, true, true, 4); else RM_LAUNCH(false, false, true, 4); }
-  else if (acc && layout == 2) { if (tile_major) RM_LAUNCH(false, true, true, 2); else RM_LAUNCH(false, false, true, 2); }
-  else if (tile_major && acc) { RM_LAUNCH(false, true, true, 0); }
-  else if (tile_major) { RM_LAUNCH(false, true, false, 0); }
-  else if (acc) { RM_LAUNCH(false, false, true, 0); }
-  else { RM_LAUNCH(false, false, false, 0); }
-#undef RM_LAUNCH
+  const bool acc = accel.dist && accel.surf && !d_counters;  // (event counts are defined on the plain algorithm)
+  with_arith(arith, true, [&](auto A) {
+    auto go = [&](auto C, auto T, auto AC, auto L) {
+      render_pass_kernel<(decltype(C)::value != 0), (decltype(T)::value != 0), (decltype(AC)::value != 0), decltype(L)::value,
+                         decltype(A)::value><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, px4, n, id0, id1,
+                                                                     tile_first, tile_stride, d_counters, accel.oct_stride,
+                                                                     seed_cast_gpu, accel.log2res);
+    };
+    if (d_counters) go(ic<1>{}, ic<0>{}, ic<0>{}, ic<0>{});
+    else if (!acc) { if (tile_major) go(ic<0>{}, ic<1>{}, ic<0>{}, ic<0>{}); else go(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}); }
+    else with_layout(layout_of(accel, false), [&](auto L) {
+      if constexpr (decltype(L)::value != 5) {  // (layout 5: frame kernel only)
+        if (tile_major) go(ic<0>{}, ic<1>{}, ic<1>{}, L); else go(ic<0>{}, ic<0>{}, ic<1>{}, L);
+      }
+    });
+  });
   return hipGetLastError();
 }
 
@@ -463,57 +483,42 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
 #ifndef RM_SDF_MINW
 #define RM_SDF_MINW 5  // (quality mode: 4 / 5 / 6 waves per SIMD measured 9.21 / 9.06 / 9.09 ms)
 #endif
-#define RM_FRAME(A, W, S, B, G) render_frame_kernel<A, W, S, B, G><<<grid, block, 0, st>>>(a)
-#define RM_FRAME_ARITH(A, W, S, B)                  \
-  do {                                              \
-    if (f.arith == 2) RM_FRAME(A, W, S, B, 2);      \
-    else if (f.arith == 1) RM_FRAME(A, W, S, B, 1); \
-    else RM_FRAME(A, W, S, B, 0);                   \
-  } while (0)
   a.log2res = f.accel.log2res;
+  const bool acc = f.accel.dist && f.accel.surf;
   if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
-    if (f.arith == 1) RM_FRAME(false, RM_SDF_MINW, true, 0, 1); else RM_FRAME(false, RM_SDF_MINW, true, 0, 0);
-  } else if (f.accel.dist && f.accel.surf && f.accel.bricked && f.accel.log2res == 9) {
-    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 3);
-  } else if (f.accel.dist && f.accel.surf && f.accel.bricked && f.accel.log2res == 10) {
-    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 4);
-  } else if (f.accel.dist && f.accel.surf && f.accel.bricked) {
-    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 1);
-  } else if (f.accel.dist && f.accel.surf && f.accel.log2res == 8 && f.accel.oct_stride) {
-    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 5);
-  } else if (f.accel.dist && f.accel.surf && f.accel.log2res) {
-    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 2);
-  } else if (f.accel.dist && f.accel.surf) {
-    RM_FRAME_ARITH(true, RM_FRAME_MINW, false, 0);
+    if (f.arith == 1) render_frame_kernel<false, RM_SDF_MINW, true, 0, 1><<<grid, block, 0, st>>>(a);
+    else render_frame_kernel<false, RM_SDF_MINW, true, 0, 0><<<grid, block, 0, st>>>(a);
   } else {
-    RM_FRAME_ARITH(false, 3, false, 0);
+    with_arith(f.arith, false, [&](auto A) {
+      if (!acc) render_frame_kernel<false, 3, false, 0, decltype(A)::value><<<grid, block, 0, st>>>(a);
+      else with_layout(layout_of(f.accel, true), [&](auto L) {
+        render_frame_kernel<true, RM_FRAME_MINW, false, decltype(L)::value, decltype(A)::value><<<grid, block, 0, st>>>(a);
+      });
+    });
   }
-#undef RM_FRAME_ARITH
-#undef RM_FRAME
   return hipGetLastError();
 }
 
 hipError_t launch_tonemap(hipStream_t st, const float* pixels, const RmOpts* d_opts, uint32_t* argb,
-                          int n, bool device_arith) {
+                          int n, int arith) {
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (device_arith) tonemap_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
-  else tonemap_kernel<false><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
+  with_arith(arith >= 2 ? arith : 0, false, [&](auto A) {  // (no seeds in TonemapImage: one CPU-device instantiation)
+    tonemap_kernel<decltype(A)::value><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
+  });
   return hipGetLastError();
 }
 
 hipError_t launch_resolve(hipStream_t st, const float* tiles, int parts, int tiles_per_part,
-                          const RmOpts* d_opts0, float* pixels, uint32_t* argb, int n, bool device_arith) {
+                          const RmOpts* d_opts0, float* pixels, uint32_t* argb, int n, int arith) {
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (device_arith)
-    resolve_kernel<true><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part, d_opts0,
-                                                 reinterpret_cast<float4*>(pixels), argb, n);
-  else
-    resolve_kernel<false><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part, d_opts0,
-                                                  reinterpret_cast<float4*>(pixels), argb, n);
+  with_arith(arith >= 2 ? arith : 0, false, [&](auto A) {
+    resolve_kernel<decltype(A)::value><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part,
+                                                               d_opts0, reinterpret_cast<float4*>(pixels), argb, n);
+  });
   return hipGetLastError();
 }
 

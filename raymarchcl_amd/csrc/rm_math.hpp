@@ -24,8 +24,19 @@
 //                  = the unmodified renderer.cl built with -ffp-contract=off and correctly rounded
 //                  divide / sqrt (tests/test_gpu_device_contract.py).
 //
+//   MathOclT<true> "this GPU, as ROCm's OpenCL compiler builds the reference BY DEFAULT" (MathOclDef): MathOcl plus
+//                  the two things clang's OpenCL defaults add to the reference source -- -ffp-contract=on fuses an
+//                  a*b+c written INSIDE ONE EXPRESSION into llvm.fmuladd (v_fma_f32 on this chip) at 15 places of
+//                  renderer.cl (M::fuse / M::fuse3 / M::nfuse3 below name each), and `/` carries !fpmath 2.5 ulp,
+//                  which AMDGPUCodeGenPrepare lowers to frexp / v_rcp_f32 / ldexp (M::div, M::inv).  Checked bit
+//                  for bit ON THE GPU against oracle/_ref/renderer_gfx950_default.hsaco = the unmodified
+//                  renderer.cl built with NO options; within 1e-4 of the reference's own -cl-fast-relaxed-math
+//                  build on ~all pixels (tests/test_gpu_contract_default.py).
+//
 // Everything that is not a built-in call in the reference source -- +, -, *, / and comparisons
-// in source order, no contraction -- is the same plain float32 code for both.
+// in source order -- is the same plain float32 code for all of them, EXCEPT at the places the
+// source spells a*b+c in one expression or divides: those go through the policy
+// (fuse/fuse3/nfuse3/div/inv: two roundings and IEEE division for the first two contracts).
 #pragma once
 #include "rm_detmath.hpp"
 
@@ -47,6 +58,14 @@ RM_DEV v3 muladd(v3 a, float s, v3 c) { return V(a.x * s + c.x, a.y * s + c.y, a
 template <int CAST>
 struct MathX86 {
   static constexpr bool kDevice = false;
+  // a*b + c / a*s + c / c - a*s written with * and + INSIDE ONE EXPRESSION of the reference source (not its mad()
+  // built-in), and the source's `/`: two roundings, IEEE division under this contract
+  RM_DEV static float fuse(float a, float b, float c) { return a * b + c; }
+  RM_DEV static v3 fuse3(v3 a, float s, v3 c) { return V(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z); }
+  RM_DEV static v3 nfuse3(v3 a, float s, v3 c) { return V(c.x - a.x * s, c.y - a.y * s, c.z - a.z * s); }
+  RM_DEV static float div(float a, float b) { return a / b; }
+  RM_DEV static float inv(float x) { return 1.0f / x; }
+  static constexpr bool kExactDiv = true;  // `/` is the IEEE quotient (rmd::div_by may stand in for it)
   RM_DEV static float mad(float a, float b, float c) { return a * b + c; }
   RM_DEV static v3 mads(v3 a, float s, v3 c) { return V(a.x * s + c.x, a.y * s + c.y, a.z * s + c.z); }
   RM_DEV static v3 madv(v3 a, v3 b, v3 c) { return V(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z); }
@@ -114,8 +133,33 @@ __device__ float ocl_fabs(float) __asm__("_Z4fabsf");
 __device__ cl_i3 ocl_convert_int3_sat(cl_f3) __asm__("_Z16convert_int3_satDv3_f");
 __device__ cl_f3 ocl_convert_float3(cl_i3) __asm__("_Z14convert_float3Dv3_i");
 
-struct MathOcl {
+// FUSED: false = the reference built with -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt ("strict"),
+//        true  = built with no options ("default"): contraction inside expressions + 2.5-ulp division
+template <bool FUSED>
+struct MathOclT {
   static constexpr bool kDevice = true;
+  static constexpr bool kExactDiv = !FUSED;
+  // clang -ffp-contract=on: a*b + c in one expression -> llvm.fmuladd -> v_fma_f32 / v_fmac_f32 (one rounding)
+  RM_DEV static float fuse(float a, float b, float c) { return FUSED ? __builtin_fmaf(a, b, c) : a * b + c; }
+  RM_DEV static v3 fuse3(v3 a, float s, v3 c) { return V(fuse(a.x, s, c.x), fuse(a.y, s, c.y), fuse(a.z, s, c.z)); }
+  // c - a*s -> fmuladd(-a, s, c)
+  RM_DEV static v3 nfuse3(v3 a, float s, v3 c) {
+    if (FUSED) return V(__builtin_fmaf(-a.x, s, c.x), __builtin_fmaf(-a.y, s, c.y), __builtin_fmaf(-a.z, s, c.z));
+    return V(c.x - a.x * s, c.y - a.y * s, c.z - a.z * s);
+  }
+  // OpenCL's `/` without -cl-fp32-correctly-rounded-divide-sqrt: fdiv !fpmath 2.5, which the gfx950 back end
+  // (f32 denormals on) expands to ldexp(frexp_mant(a) * rcp(frexp_mant(b)), frexp_exp(a) - frexp_exp(b)),
+  // and 1.0f / x to ldexp(rcp(frexp_mant(x)), -frexp_exp(x))  (AMDGPUCodeGenPrepare emitFrexpDiv / emitRcpIEEE1ULP)
+  RM_DEV static float div(float a, float b) {
+    if (!FUSED) return a / b;
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(b));
+    const float q = __builtin_amdgcn_frexp_mantf(a) * r;
+    return __builtin_amdgcn_ldexpf(q, __builtin_amdgcn_frexp_expf(a) - __builtin_amdgcn_frexp_expf(b));
+  }
+  RM_DEV static float inv(float x) {
+    if (!FUSED) return 1.0f / x;
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(x)), -__builtin_amdgcn_frexp_expf(x));
+  }
   RM_DEV static cl_f3 v(v3 a) { cl_f3 r = {a.x, a.y, a.z}; return r; }
   RM_DEV static v3 u(cl_f3 a) { return V(a.x, a.y, a.z); }
   RM_DEV static cl_f3 splat(float s) { cl_f3 r = {s, s, s}; return r; }
@@ -159,5 +203,19 @@ struct MathOcl {
     if (sp != sp) steps = 0;
   }
 };
+using MathOcl = MathOclT<false>;
+using MathOclDef = MathOclT<true>;
+
+// The contract of a context as the kernels are instantiated on it (ARITH): one table, used by every launcher
+//   0  MathX86<0>  OpenCL CPU device                  1  MathX86<1>  the same, GPU lowering of the seed casts
+//   2  MathOcl     this GPU, strict reference build   3  MathOclDef  this GPU, default reference build
+//   4  MathX86<2>  OpenCL CPU device, seed-cast lowering chosen at run time (single-pass parity kernels)
+constexpr int kArithCount = 4;  // 0..3 reach the frame kernel
+template <int ARITH> struct ArithOf;
+template <> struct ArithOf<0> { using type = MathX86<0>; };
+template <> struct ArithOf<1> { using type = MathX86<1>; };
+template <> struct ArithOf<2> { using type = MathOcl; };
+template <> struct ArithOf<3> { using type = MathOclDef; };
+template <> struct ArithOf<4> { using type = MathX86<2>; };
 
 }  // namespace rmk

@@ -2,8 +2,9 @@
 // behaviour of the reference device functions
 // (/root/reference/resources/renderer.cl:142-476; the function each routine
 // replaces is cited next to it).  Scalar float32 throughout, every expression
-// in the reference's evaluation order, no FMA contraction; the value of the reference's math
-// built-ins comes from the arithmetic contract M (rm_math.hpp: OpenCL CPU device / this GPU).
+// in the reference's evaluation order; the value of the reference's math built-ins, of its `/` and of the
+// a*b+c it spells inside one expression (which ITS compiler may contract) comes from the arithmetic
+// contract M (rm_math.hpp: OpenCL CPU device / this GPU, strict or default build of the reference).
 //
 // One lane owns one sample from camera ray to final colour (shade()); in the frame kernel
 // the AO probes and shadow rays of a wavefront's hits are traced by all its lanes
@@ -55,10 +56,10 @@ RM_DEV Material material_of(const RmOpts& o, int id, bool* oob = nullptr) {
 // slab test: renderer.cl:153-161
 template <class M>
 RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
-  const float lox = (o.voxelBoundsMin[0] - p.x) / d.x, loy = (o.voxelBoundsMin[1] - p.y) / d.y,
-              loz = (o.voxelBoundsMin[2] - p.z) / d.z;
-  const float hix = (o.voxelBoundsMax[0] - p.x) / d.x, hiy = (o.voxelBoundsMax[1] - p.y) / d.y,
-              hiz = (o.voxelBoundsMax[2] - p.z) / d.z;
+  const float lox = M::div(o.voxelBoundsMin[0] - p.x, d.x), loy = M::div(o.voxelBoundsMin[1] - p.y, d.y),
+              loz = M::div(o.voxelBoundsMin[2] - p.z, d.z);
+  const float hix = M::div(o.voxelBoundsMax[0] - p.x, d.x), hiy = M::div(o.voxelBoundsMax[1] - p.y, d.y),
+              hiz = M::div(o.voxelBoundsMax[2] - p.z, d.z);
   const float nx = M::fmin(hix, lox), ny = M::fmin(hiy, loy), nz = M::fmin(hiz, loz);
   const float a = M::fmax(M::fmax(nx, 0.0f), M::fmax(ny, nz));
   const float fx = M::fmax(hix, lox), fy = M::fmax(hiy, loy), fz = M::fmax(hiz, loz);
@@ -72,13 +73,13 @@ RM_DEV bool in_grid_of(const RmOpts& o, int qx, int qy, int qz) {  // 0 <= q < r
 // renderer.cl:259-261
 template <class M>
 RM_DEV v3 sky_of(const RmOpts& o, v3 dir) {
-  return M::mixs(ld3(o.skyColor1), ld3(o.skyColor2), dir.y * 0.5f + 0.5f);
+  return M::mixs(ld3(o.skyColor1), ld3(o.skyColor2), M::fuse(dir.y, 0.5f, 0.5f));
 }
 // renderer.cl:271-273
 template <class M>
 RM_DEV v3 reflect_of(v3 v, v3 n) {
   const float k = 2.0f * M::dot(v, n);
-  return v - n * k;
+  return M::nfuse3(n, k, v);  // v - 2.0f * dot(v, n) * n
 }
 // renderer.cl:304-311
 template <class M>
@@ -493,11 +494,11 @@ struct Tracer {
       const float sf = (float)steps * 0.5f;
       const v3 ivs = ld3(o.invVoxelScale);
       v3 delta;
-      if (ACCEL) {
+      if (ACCEL && M::kExactDiv) {  // (the IEEE quotients in three instructions each)
         const rmd::Divisor by_sf = rmd::make_divisor(sf);
         delta = V(rmd::div_by(dir.x, by_sf), rmd::div_by(dir.y, by_sf), rmd::div_by(dir.z, by_sf)) * ivs;
       } else {
-        delta = V(dir.x / sf, dir.y / sf, dir.z / sf) * ivs;
+        delta = V(M::div(dir.x, sf), M::div(dir.y, sf), M::div(dir.z, sf)) * ivs;
       }
       v3 p = rpos + ld3(o.voxelBounds);
       if (t_in > 0.0f) p = mads(dir, t_in, p);
@@ -679,7 +680,7 @@ struct Tracer {
         do {
           maxSteps--;
           last_t = dist;
-          const float h = (rdir.y * dist + ro.y) + o.groundY;  // y of renderer.cl:244, then :211
+          const float h = M::fuse(rdir.y, dist, ro.y) + o.groundY;  // y of renderer.cl:244, then :211
           g = h < 1e5f ? h : 1e5f;
           nw = kFilter && surely_no_walk(flt, dist, g);
           go = nw & !((__builtin_fabsf(g) <= o.eps) | (dist >= maxDist));
@@ -702,28 +703,28 @@ struct Tracer {
       // is a filtered one or finds its hit close by)
       if (ACCEL && !distance_only) limit = walk_limit_from(g, spu);
       cut_last = false;
-      scene_distance(muladd(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
+      scene_distance(M::fuse3(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
                      &cut_last);
       last_kind = 1;
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }
       dist += sd;
     }
     if (maxSteps != turns0) {  // at least one turn: renderer.cl:244-246 values of the last one
-      r.pos = muladd(rdir, last_t, ro);
+      r.pos = M::fuse3(rdir, last_t, ro);
       if (ACCEL && !distance_only && last_kind == 1 && cut_last) {
         float sd2, sc2;
         scene_distance(r.pos, rdir, o.maxVoxelIter, smooth, sd2, sc2, r.normal);
       }
       if (SDFM && last_kind == 1 && cut_last) r.normal = sdf_gradient(r.pos);  // (r.pos is the last estimate's position, bit for bit)
       if (last_kind == 0) {  // renderer.cl:211-212 for the ground / sky term
-        const float h = (rdir.y * last_t + ro.y) + o.groundY;
+        const float h = M::fuse(rdir.y, last_t, ro.y) + o.groundY;
         scode = h < 1e5f ? h : -1.0f;
         r.normal = (h < 1e5f) ? V(0.f, 1.f, 0.f) : -rdir;
       }
       r.objectID = M::to_int(scode);
     }
     if (dist >= maxDist) {
-      r.pos = muladd(rdir, dist, ro);
+      r.pos = M::fuse3(rdir, dist, ro);
       r.objectID = -1;
       dist = 1000.0f;
     }
@@ -738,7 +739,7 @@ struct Tracer {
   // jittered light position: renderer.cl:263-269
   RM_DEV v3 light_at(const Sample& s, int i) {
     const RmOpts& o = *sc.o;
-    const uint32_t seed = seed_of(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f);
+    const uint32_t seed = seed_of(M::fuse(s.time, 4763.742f, M::fuse(s.px, 1957.0f, s.py * 2173.0f)));
     const float4 r = table(seed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
@@ -754,7 +755,7 @@ struct Tracer {
       v3 lp = light_at(s, i);
       const float d = M::clamp(dot(lp - ro, rdir), 0.0f, dist);
       lp = mads(rdir, d, ro - lp);
-      const float k = o.flareAmp / dot(lp, lp);
+      const float k = M::div(o.flareAmp, dot(lp, lp));
       col = mads(ld3(o.lightColor[i]), k, col);
     }
     return col;
@@ -776,7 +777,7 @@ struct Tracer {
     float ao = 1.0f;
     float d = 0.0f;
     uint32_t seed =
-        seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+        seed_of(M::fuse(s.time, 2671.918f, M::fuse(pos.z, 2945.87f, M::fuse(pos.x, 3183.75f, pos.y * 1831.42f))));
     for (int i = 0; i <= o.aoIter && (double)ao > 0.01; i++) {
       d += o.aoStepDist;
       seed += 37u;
@@ -787,7 +788,7 @@ struct Tracer {
       const v3 rpos = mads(n, d, pos);
       scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false,
                      ACCEL ? ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2) : 0x7fffffff);
-      ao *= 1.0f - M::fmax((d - sd) * o.aoAmp / d, 0.0f);
+      ao *= 1.0f - M::fmax(M::div((d - sd) * o.aoAmp, d), 0.0f);
     }
     return ao;
   }
@@ -803,23 +804,23 @@ struct Tracer {
     for (int i = 0; i < nl; i++) {
       const v3 dl = light_at(s, i) - hitpos;
       const float d2 = dot(dl, dl);
-      const float att = 1.0f / d2;
+      const float att = M::inv(d2);
       if (att > o.minLightAtt) {
         const v3 ldir = normalize(dl);
         const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
-        const float sh = SDFM ? soft_shadow_sdf(muladd(ldir, o.shadowBias, hitpos), ldir, lmax)
-                              : shadow_term(muladd(ldir, o.shadowBias, hitpos), ldir, lmax);
+        const float sh = SDFM ? soft_shadow_sdf(M::fuse3(ldir, o.shadowBias, hitpos), ldir, lmax)
+                              : shadow_term(M::fuse3(ldir, o.shadowBias, hitpos), ldir, lmax);
         if (sh > 0.0f) {
           const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-          diff = diff + inc * M::fmax(0.0f, dot(ldir, normal));
-          spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+          diff = M::fuse3(inc, M::fmax(0.0f, dot(ldir, normal)), diff);  // diffReflect += intensity * incidentLight
+          spec = M::fuse3(inc, blinn_phong(m.smoothness, raydir, ldir, normal), spec);
         }
       }
       diff = diff * m.albedo;
       out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
     }
     const float fl = (float)nl;
-    return V(out.x / fl, out.y / fl, out.z / fl);
+    return V(M::div(out.x, fl), M::div(out.y, fl), M::div(out.z, fl));
   }
   // one reflection bounce: renderer.cl:383-405
   RM_DEV v3 bounce_colour(const Sample& s, v3 ro, v3 rdir, Hit& h) {
@@ -845,7 +846,7 @@ struct Tracer {
     } else {
       if (COUNT) cnt.primary_hits++;
       const Material m = material(h.objectID);
-      const float k = 1.0f / M::mad(m.smoothness, 200.0f, 5.0f);
+      const float k = M::inv(M::mad(m.smoothness, 200.0f, 5.0f));
       const v3 norm = mads(s.mcNormal, k, h.normal);
       v3 refl = V(0.f, 0.f, 0.f);
       if (m.r0 > 0.0f && o.reflectIter > 0) {
@@ -855,7 +856,7 @@ struct Tracer {
         v3 dir = rdir;
         for (int i = 0; i < o.reflectIter; i++) {
           dir = reflect(dir, rh.normal);
-          const v3 from = muladd(dir, 0.0075f, rh.pos);
+          const v3 from = M::fuse3(dir, 0.0075f, rh.pos);
           refl = refl + bounce_colour(s, from, dir, rh);
           if (rh.objectID < 0) break;
           if ((double)material(rh.objectID).r0 < 0.001) break;
@@ -887,11 +888,11 @@ struct Tracer {
     const RmOpts& o = *sc.o;
     const v3 fwd = normalize(ld3(o.targetPos) - s.eye);
     const v3 right = normalize(cross(fwd, ld3(o.up)));
-    float vx = s.px / (float)o.resolution[0] * o.fov - o.fov * 0.5f;
-    float vy = s.py / (float)o.resolution[1] * o.fov - o.fov * 0.5f;
+    float vx = M::fuse(M::div(s.px, (float)o.resolution[0]), o.fov, -(o.fov * 0.5f));  // pixelPos / res * fov - fov * 0.5f
+    float vy = M::fuse(M::div(s.py, (float)o.resolution[1]), o.fov, -(o.fov * 0.5f));
     vy *= -o.invAspect;
     const v3 upv = cross(right, fwd);
-    return normalize(right * vx + upv * vy + fwd);
+    return normalize(M::fuse3(right, vx, upv * vy) + fwd);  // (right * x + up * y) + forward
   }
 
   // =====================================================================================
@@ -954,7 +955,7 @@ struct Tracer {
     if (dl.owners == 0) return 1.0f;
     // (np <= kWaveLdsRes: the host sends frames whose records ask for more probes through the single-pass kernels)
     const uint32_t seed0 =
-        seed_of(pos.x * 3183.75f + pos.y * 1831.42f + pos.z * 2945.87f + s.time * 2671.918f);
+        seed_of(M::fuse(s.time, 2671.918f, M::fuse(pos.z, 2945.87f, M::fuse(pos.x, 3183.75f, pos.y * 1831.42f))));
     if (active) {
       lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
       lds_in(3, dl.lane) = normal.x; lds_in(4, dl.lane) = normal.y; lds_in(5, dl.lane) = normal.z;
@@ -999,7 +1000,7 @@ struct Tracer {
       float d = 0.0f;
       for (int i = 0; i < np && (double)ao > 0.01; i++) {  // renderer.cl:338-344
         d += o.aoStepDist;
-        ao *= 1.0f - M::fmax((d - lds_res(i, dl.lane)) * o.aoAmp / d, 0.0f);
+        ao *= 1.0f - M::fmax(M::div((d - lds_res(i, dl.lane)) * o.aoAmp, d), 0.0f);
       }
     }
     wave_sync();  // the posted values are dead: the next shared phase may overwrite them
@@ -1039,15 +1040,15 @@ struct Tracer {
         // the expressions of lighting() (renderer.cl:356-362)
         const v3 dlv = mads(ojit, o.lightScatter, ld3(o.lightPos[light])) - opos;
         const float d2 = dot(dlv, dlv);
-        const float att = 1.0f / d2;
+        const float att = M::inv(d2);
         if (att > o.minLightAtt) {
           const v3 ldir = normalize(dlv);
           const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
           if (SDFM) {  // quality mode: the penumbra estimate itself is the task's result
-            lds_res(light, owner) = soft_shadow_sdf(muladd(ldir, o.shadowBias, opos), ldir, lmax);
+            lds_res(light, owner) = soft_shadow_sdf(M::fuse3(ldir, o.shadowBias, opos), ldir, lmax);
           } else {
             Hit h{};
-            march(muladd(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
+            march(M::fuse3(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
             lds_res(light, owner) = h.distance;
           }
         }
@@ -1065,7 +1066,7 @@ struct Tracer {
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
-      const float4 r = table(seed_of(s.px * 1957.0f + s.py * 2173.0f + s.time * 4763.742f));
+      const float4 r = table(seed_of(M::fuse(s.time, 4763.742f, M::fuse(s.px, 1957.0f, s.py * 2173.0f))));
       jit = V(r.x, r.y, r.z);
     }
     // Which (hit, light) pairs need their shadow march at all.  A pair whose diffuse and
@@ -1086,7 +1087,7 @@ struct Tracer {
       unsigned int dark = 0u;
       for (int i = 0; i < o.numLights && i < 4; i++) {
         const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
-        const float att = 1.0f / dot(dl, dl);
+        const float att = M::inv(dot(dl, dl));
         if (att > o.minLightAtt) {
           need |= 1u << i;
           const v3 ldir = normalize(dl);
@@ -1111,22 +1112,22 @@ struct Tracer {
       for (int i = 0; i < nl; i++) {
         const v3 dl = mads(jit, o.lightScatter, ld3(o.lightPos[i])) - hitpos;
         const float d2 = dot(dl, dl);
-        const float att = 1.0f / d2;
+        const float att = M::inv(d2);
         if (att > o.minLightAtt) {
           const v3 ldir = normalize(dl);
           const float lmax = M::fmin(M::sqrt(d2) - o.shadowBias, o.maxDist);
           const float sh = SDFM ? lds_res(i, lane) : M::step(lmax, lds_res(i, lane));
           if (sh > 0.0f) {
             const v3 inc = (ld3(o.lightColor[i]) * sh) * att;
-            diff = diff + inc * M::fmax(0.0f, dot(ldir, normal));
-            spec = spec + inc * blinn_phong(m.smoothness, raydir, ldir, normal);
+            diff = M::fuse3(inc, M::fmax(0.0f, dot(ldir, normal)), diff);  // diffReflect += intensity * incidentLight
+            spec = M::fuse3(inc, blinn_phong(m.smoothness, raydir, ldir, normal), spec);
           }
         }
         diff = diff * m.albedo;
         out = out + mixs(diff, spec, schlick(m.r0, m.smoothness, normal, raydir));
       }
       const float fl = (float)nl;
-      res = V(out.x / fl, out.y / fl, out.z / fl);
+      res = V(M::div(out.x, fl), M::div(out.y, fl), M::div(out.z, fl));
     }
     wave_sync();  // results consumed before the next shared phase posts
     return res;
@@ -1144,7 +1145,7 @@ struct Tracer {
     float r0 = 0.0f;
     if (hit) {
       const Material m = material(h.objectID);
-      const float k = 1.0f / M::mad(m.smoothness, 200.0f, 5.0f);
+      const float k = M::inv(M::mad(m.smoothness, 200.0f, 5.0f));
       norm = mads(s.mcNormal, k, h.normal);
       r0 = m.r0;
     }
@@ -1161,7 +1162,7 @@ struct Tracer {
         v3 from = V(0.f, 0.f, 0.f);
         if (alive) {
           dir = reflect(dir, rh.normal);
-          from = muladd(dir, 0.0075f, rh.pos);
+          from = M::fuse3(dir, 0.0075f, rh.pos);
           march(from, dir, rh, o.maxDist, o.maxIter, false);  // bounce_colour(), renderer.cl:383-405
         }
         const bool bhit = alive && rh.objectID >= 0;
