@@ -14,7 +14,9 @@ are interleaved over the ranks and the tile accumulators are gathered on rank
 0 over RCCL -- the total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.  `value` = primary rays (= samples) per second
-of the whole job; `roofline` prices the dominant kernel (render_frame_kernel:
+of the whole job with ONE BLOCKING FRAME PER STEP (launch .. result on the device, the way the
+reference's loop runs its pipeline, core.clj:203-208; the frame period with several frames in
+flight is reported under `pipelined`, never as `value`); `roofline` prices the dominant kernel (render_frame_kernel:
 all RenderImage passes of the frame in one launch) against HBM bandwidth using
 the ALGORITHMIC bytes of the reference algorithm for that launch (DESIGN.md);
 `cpu_baseline` is the CPU restatement of the reference kernel (oracle/) timed
@@ -131,20 +133,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="successive frames alternate between this many HIP streams (1 = strictly serial; "
-                         "default 3 on one GPU, 2 per rank on several -- measured best)")
+                    help="the extra `pipelined` leg: successive frames alternate between this many HIP streams "
+                         "(default 3 on one GPU, 2 per rank on several -- measured best; 1 = leg skipped).  The "
+                         "timed region behind `value` is always ONE BLOCKING FRAME AT A TIME, as the reference's loop "
+                         "runs its pipeline (core.clj:203-208)")
     ap.add_argument("--backend", default="ranks", choices=["ranks", "library"],
                     help="ranks: one process per GPU, torch.distributed (RCCL) gather of the tile accumulators; "
                          "library: ONE process, the frame tiled over N devices inside the C library "
                          "(rm_create_multi: peer copies over xGMI, no RCCL) -- what a JNI caller gets")
-    ap.add_argument("--contract", default="gfx950", choices=["cpu", "gfx950"],
-                    help="arithmetic contract of the kernels (include/raymarch_hip.h rm_set_contract): cpu = the "
-                         "results of an OpenCL CPU device (checked against the CPU oracle), gfx950 = the results of "
-                         "the reference kernel built by ROCm's OpenCL compiler for this GPU (checked against that "
-                         "build on the GPU)")
+    ap.add_argument("--contract", default="gfx950-default", choices=["cpu", "gfx950-default", "gfx950-strict"],
+                    help="arithmetic contract of the kernels (include/raymarch_hip.h rm_set_contract): gfx950-default "
+                         "(the library default) / gfx950-strict = the results of the reference kernel as ROCm's OpenCL "
+                         "compiler builds it for this GPU with no options / with -ffp-contract=off and correctly "
+                         "rounded divide+sqrt (each checked bit for bit against that build on the GPU); cpu = the "
+                         "results of an OpenCL CPU device (checked against the CPU oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -182,7 +187,7 @@ def main():
         # -5 %), but with volumes far beyond the caches concurrent frames evict each other
         # (512^3: +5 %, 1024^3: +7 %)
         big = WORKLOADS[args.workload]["vres"] ** 3 > (64 << 20)
-        args.frames_in_flight = 1 if big else (3 if world == 1 else 2)
+        args.frames_in_flight = 1 if big else (3 if world == 1 else 2)  # (the `pipelined` leg only)
 
     # (no-op when the library is current; several ranks must not rebuild the same file at once)
     if world == 1 or rank == 0:
@@ -192,9 +197,10 @@ def main():
     wl = WORKLOADS[args.workload]
     vox, vres, opts, mc = build_inputs(wl)
     n, width, spp = wl["w"] * wl["h"], wl["w"], wl["spp"]
+    # `value`: one frame at a time -- the reference's loop runs execute-pipeline and takes its result per frame
+    # (core.clj:203-208), so a step is a BLOCKING frame: launch, (gather, resolve,) wait
     fr = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev,
-                                want_pixels=True, want_argb=True, frames_in_flight=args.frames_in_flight,
-                                contract=args.contract)
+                                want_pixels=True, want_argb=True, frames_in_flight=1, contract=args.contract)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -202,20 +208,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        fr.render()
-    sync_all()
+    def timed_steps(renderer, blocking):
+        """W untimed + K timed steps between barrier + synchronize on both sides -> seconds, max over ranks."""
+        for _ in range(args.warmup):
+            renderer.render()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            renderer.render()
+            if blocking:
+                torch.cuda.synchronize(dev)  # this frame's result is there before the next frame starts
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
     kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fr.render()
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = timed_steps(fr, blocking=True)
+    # the same frames enqueued back to back on several streams (an animation loop that does not wait per frame):
+    # reported beside the headline, never `value`
+    pipelined = None
+    if args.frames_in_flight > 1:
+        fp = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev, want_pixels=True,
+                                    want_argb=True, frames_in_flight=args.frames_in_flight, contract=args.contract)
+        p_elapsed = timed_steps(fp, blocking=False)
+        fp.close()
+        pipelined = {"frames_in_flight": args.frames_in_flight, "ms_per_step": round(p_elapsed / args.steps * 1e3, 4),
+                     "value": round(n * spp * args.steps / p_elapsed / 1e6, 3), "unit": "Mrays/s",
+                     "note": "frame PERIOD with successive frames in flight on separate HIP streams (the tail of one "
+                             "launch overlaps the head of the next); no frame finishes sooner than ms_per_step of the headline"}
 
     # Dominant kernel: render_frame_kernel.  HIP events bracket its launch(es) of a frame on the
     # stream they run on (the slot's stream, handed to the library); measured on extra frames
@@ -251,16 +275,8 @@ def main():
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
         fa = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, rank=rank, world=world, device=dev,
-                                    want_pixels=False, want_argb=True, frames_in_flight=args.frames_in_flight,
-                                    contract=args.contract)
-        for _ in range(args.warmup):
-            fa.render()
-        sync_all()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            fa.render()
-        sync_all()
-        ta = time.perf_counter() - ta
+                                    want_pixels=False, want_argb=True, frames_in_flight=1, contract=args.contract)
+        ta = timed_steps(fa, blocking=True)
         arows = []
         for _ in range(4):
             sync_all()
@@ -316,13 +332,14 @@ def main():
             "config": {"workload": wl["desc"], "volume": f"{vres[0]}^3 u8", "resolution": [wl["w"], wl["h"]],
                        "spp": spp, "partition": f"8x8 tiles interleaved over {world} GPU(s)" + ((", gloo gather through the host (BENCH_ONE_DEVICE rehearsal: all ranks on one GPU)" if rehearsal
                                      else ", RCCL gather to rank 0") if world > 1 else ""),
-                       "contract": args.contract + (" (OpenCL CPU device semantics; bit-exact vs the CPU oracle)" if args.contract == "cpu"
-                                                    else " (ROCm OpenCL on this GPU; bit-exact vs the reference kernel built for gfx950)"),
-                       "frames_in_flight": len(fr.slots),
-                       "overlap": ("none: frames are strictly serial" if len(fr.slots) == 1 else
-                                   f"ms_per_step is the frame period with {len(fr.slots)} successive frames in flight "
-                                   "on separate HIP streams (the tail of one launch overlaps the head of the "
-                                   "next); ms_per_frame_serial and roofline.kernel_ms are one frame alone")},
+                       "contract": args.contract + {
+                           "cpu": " (OpenCL CPU device semantics; bit-exact vs the CPU oracle)",
+                           "gfx950-default": " (ROCm OpenCL on this GPU; bit-exact vs the reference kernel built for gfx950 with no "
+                                             "options, which is within 1e-4 of the reference's own fast-math build on ~all pixels)",
+                           "gfx950-strict": " (ROCm OpenCL on this GPU; bit-exact vs the reference kernel built for gfx950 with "
+                                            "-ffp-contract=off and correctly rounded divide/sqrt)"}[args.contract],
+                       "frames_in_flight": 1,
+                       "overlap": "none: every timed step is one blocking frame (launch .. result), as core.clj:203-208 runs it"},
             "all_rays_per_s_M": round((c["rays"] + c["ao_calls"]) * args.steps / elapsed / 1e6, 2),
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -335,6 +352,8 @@ def main():
                 "table_reads_per_sample": round(c["mc_reads"] / samples_per_frame, 2),
             },
         }
+        if pipelined:
+            out["pipelined"] = pipelined
         if per_rank:
             out["per_rank"] = per_rank
             out["argb_exchange"] = argb_exchange
@@ -383,18 +402,21 @@ def main():
                                             "rm_pin_host_buffer; _argb_only: pinned, pixels_out = NULL -- only the 3.7 MB ARGB image comes back, "
                                             "which is all the reference's pipeline reads (core.clj:91-97)"}
         if world == 1:
-            # the other arithmetic contract, same frame, strictly serial (reported, never `value`)
-            other = "cpu" if args.contract == "gfx950" else "gfx950"
-            fo = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, device=dev, frames_in_flight=1, contract=other)
-            oms = []
-            for _ in range(6):
-                fo.render()
-                torch.cuda.synchronize(dev)
-                oms.append(fo.ctx.last_frame_timing()[0])
-            fo.close()
-            out["other_contract"] = {"contract": other, "kernel_ms": round(float(np.median(oms[1:])), 4),
-                                     "note": "both contracts are parity-checked bit for bit, each against its own "
-                                             "reference build (tests/test_gpu_device_contract.py, test_gpu_configs.py)"}
+            # the other arithmetic contracts, same frame, strictly serial (reported, never `value`)
+            out["other_contract"] = []
+            for other in ("gfx950-default", "gfx950-strict", "cpu"):
+                if other == args.contract:
+                    continue
+                fo = multigpu.FrameRenderer(vox, vres, opts, mc, n, width, device=dev, frames_in_flight=1, contract=other)
+                oms = []
+                for _ in range(6):
+                    fo.render()
+                    torch.cuda.synchronize(dev)
+                    oms.append(fo.ctx.last_frame_timing()[0])
+                fo.close()
+                out["other_contract"].append({"contract": other, "kernel_ms": round(float(np.median(oms[1:])), 4)})
+            out["other_contract_note"] = ("every contract is parity-checked bit for bit against its own checker "
+                                          "(tests/test_gpu_device_contract.py, test_gpu_configs.py)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vox, opts, mc, n, spp, args.cpu_passes)
     if rank == 0:
@@ -460,9 +482,9 @@ def library_bench(args):
         frame()
     ctx.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):  # one blocking frame at a time (core.clj:203-208), like the ranks backend
         frame()
-    ctx.synchronize()
+        ctx.synchronize()
     elapsed = time.perf_counter() - t0
     kms, serial = [], []
     for _ in range(5):

@@ -1,0 +1,108 @@
+"""oracle.pin -- TEST INFRASTRUCTURE: the checkers of the two device contracts.
+
+A device contract of the product is pinned to a BUILD of the unmodified reference kernel for gfx950:
+
+  build "strict"   RM_CONTRACT_GFX950_STRICT   renderer.cl compiled with -ffp-contract=off
+                                                -cl-fp32-correctly-rounded-divide-sqrt
+  build "default"  RM_CONTRACT_GFX950_DEFAULT  renderer.cl compiled with NO options (clang's OpenCL defaults:
+                                                contraction inside expressions, 2.5-ulp divide); agrees with the
+                                                reference's own -cl-fast-relaxed-math build within 1e-4 on ~all pixels
+
+Two sources per build, in this order:
+  1. LIVE   oracle/_ref/renderer_gfx950_<build>.hsaco -- compiled by oracle/Makefile in the build container
+            (git-ignored, travels with the snapshot), run on the GPU through oracle/ref_gfx950_runner.cpp;
+  2. FIXED  tests/golden/gfx950_<build>/ -- the outputs of exactly that code object on the same inputs, recorded
+            ON the GPU by tests/golden/make_golden_gfx950.py and committed (data only): full float32 accumulators
+            + ARGB words for the fixture scenes and config 1, sha256 digests (digests.json) + a sparse sample of
+            pixels (digest_samples.npz) for the large frames (configs 2-5, pass-packed frames).
+A clean clone on a GPU box therefore still checks every device-contract frame bit for bit; when neither source
+exists the check raises CheckerMissing (an AssertionError: tests FAIL, they do not skip -- a GPU box without a
+checker is a broken checkout, not a reason to pass).
+
+No pytest here: __graft_entry__.smoke() uses this module too.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAMPLE_STRIDE = 997  # pixels kept from a digest-pinned frame (prime: walks through rows and columns)
+BUILDS = ("strict", "default")
+CONTRACT_OF = {"strict": "gfx950-strict", "default": "gfx950-default"}  # raymarchcl_amd._native.CONTRACTS names
+
+
+class CheckerMissing(AssertionError):
+    pass
+
+
+def fixed_dir(build):
+    return os.path.join(ROOT, "tests", "golden", "gfx950_" + build)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def input_digest(vox, opts, mc, n):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(vox).tobytes())
+    h.update(bytes(opts))
+    h.update(np.ascontiguousarray(mc, dtype=np.float32).tobytes())
+    h.update(str(int(n)).encode())
+    return h.hexdigest()
+
+
+class Checker:
+    def __init__(self, oracle_mod, build="strict", fixed=None):
+        assert build in BUILDS, build
+        self.oracle = oracle_mod
+        self.build = build
+        self.fixed = fixed or fixed_dir(build)
+        self.live = bool(oracle_mod.have_gfx950_ref(build)) and os.environ.get("RAYMARCH_PIN_FIXED_ONLY", "0") != "1"
+
+    def source(self):
+        return f"live `{self.build}` reference build" if self.live else f"committed recordings of the `{self.build}` build"
+
+    def _digests(self):
+        p = os.path.join(self.fixed, "digests.json")
+        return json.load(open(p)) if os.path.exists(p) else {}
+
+    def frame(self, key, vox, opts, mc, n):
+        """-> (pixels float32[4n], argb uint32[n]) of the reference build for these inputs;
+        only for keys whose full output is on file (fixture scenes, c1)."""
+        if self.live:
+            px, argb, _ = self.oracle.gfx950_render_frame(vox, opts, mc, n, build=self.build)
+            return px, argb
+        path = os.path.join(self.fixed, key + ".npz")
+        if not os.path.exists(path):
+            raise CheckerMissing(f"no device-contract checker for `{key}`: neither oracle/_ref/renderer_gfx950_{self.build}.hsaco "
+                                 f"nor {os.path.relpath(path, ROOT)} exists")
+        z = np.load(path)
+        assert str(z["inputs"]) == input_digest(vox, opts, mc, n), f"fixture {key} was recorded for other inputs"
+        return z["pixels"].copy(), z["argb"].copy()
+
+    def assert_frame(self, key, vox, opts, mc, n, px, argb):
+        """The product's (px, argb) equal the reference build's, bit for bit.  Full comparison
+        when the reference is live or the fixture holds the frame; digest + sample otherwise."""
+        px = np.asarray(px, dtype=np.float32).reshape(-1)
+        if self.live or os.path.exists(os.path.join(self.fixed, key + ".npz")):
+            want, want_argb = self.frame(key, vox, opts, mc, n)
+            bad = int((px.view(np.uint32) != want.view(np.uint32)).reshape(-1, 4).any(axis=1).sum())
+            assert bad == 0, f"{key}: {bad} pixels differ from the reference build ({self.source()})"
+            if argb is not None:
+                assert np.array_equal(argb, want_argb), key
+            return
+        d = self._digests().get(key)
+        if d is None:
+            raise CheckerMissing(f"no device-contract checker for `{key}`: oracle/_ref is absent and "
+                                 f"{os.path.relpath(self.fixed, ROOT)}/digests.json has no entry")
+        assert d["inputs"] == input_digest(vox, opts, mc, n), f"digest of {key} was recorded for other inputs"
+        sample = np.load(os.path.join(self.fixed, "digest_samples.npz"))[key]
+        got = px.view(np.uint32).reshape(-1, 4)[::SAMPLE_STRIDE].reshape(-1)
+        where = np.nonzero(got != sample)[0]
+        assert where.size == 0, f"{key}: sampled pixel {int(where[0]) // 4 * SAMPLE_STRIDE} differs from the reference build"
+        assert sha(px) == d["pixels_sha"], f"{key}: accumulator digest differs from the reference build's"
+        if argb is not None:
+            assert sha(np.asarray(argb, dtype=np.uint32)) == d["argb_sha"], f"{key}: ARGB digest differs"

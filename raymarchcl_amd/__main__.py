@@ -43,11 +43,12 @@ def main(argv=None):
     r.add_argument("--gamma", type=float, default=None)
     r.add_argument("--seed", type=int, default=1000, help="seed of the scatter tables")
     r.add_argument("--device", type=int, default=0)
-    r.add_argument("--contract", default="gfx950", choices=["cpu", "gfx950"],
-                   help="whose results the kernels reproduce: gfx950 (default) = the reference kernel built by ROCm's "
-                        "OpenCL compiler for this GPU with -ffp-contract=off and correctly rounded divide/sqrt (NOT the "
-                        "reference's own -cl-fast-relaxed-math build, which no implementation can equal bit for bit); "
-                        "cpu = an OpenCL CPU device on x86-64 (include/raymarch_hip.h rm_set_contract)")
+    r.add_argument("--contract", default="gfx950-default", choices=["cpu", "gfx950-default", "gfx950-strict", "gfx950"],
+                   help="whose results the kernels reproduce, bit for bit: gfx950-default (default) = the reference kernel as "
+                        "ROCm's OpenCL compiler builds it for this GPU with no options (within 1e-4 of the reference's own "
+                        "-cl-fast-relaxed-math build on ~all pixels); gfx950-strict (= gfx950) = the same built with "
+                        "-ffp-contract=off and correctly rounded divide/sqrt; cpu = an OpenCL CPU device on x86-64 "
+                        "(include/raymarch_hip.h rm_set_contract)")
     args = ap.parse_args(argv)
 
     from . import core, generators, vio

@@ -233,7 +233,7 @@ def _np(a, dtype, name):
 
 
 # Arithmetic contract applied to every Context created without an explicit one; None = the
-# library's own default (RM_CONTRACT_GFX950).  Test modules that check the CPU-device contract
+# library's own default (RM_CONTRACT_GFX950_DEFAULT).  Test modules that check the CPU-device contract
 # against the CPU oracle set this to "cpu" for their duration.
 DEFAULT_CONTRACT = None
 
@@ -243,7 +243,7 @@ class Context:
 
     def __init__(self, device_id=0, contract=None):
         """device_id: a HIP ordinal, or a sequence of ordinals for one frame spread over several
-        devices (rm_create_multi; ordinals may repeat).  contract: "gfx950" (library default) / "cpu"."""
+        devices (rm_create_multi; ordinals may repeat).  contract: a key of CONTRACTS; None = "gfx950-default" (the library's)."""
         self._h = _vp()
         if isinstance(device_id, (list, tuple)):
             ids = (_i * len(device_id))(*[int(d) for d in device_id])
@@ -381,10 +381,10 @@ class Context:
                                     _np(argb, np.uint32, "argb") if argb is not None else None))
 
     def set_contract(self, contract):
-        """"gfx950" (default): the results of the reference kernel built by ROCm's OpenCL compiler for
-        this GPU with -ffp-contract=off and correctly rounded divide/sqrt (checked bit for bit against
-        that build); "cpu": the results of an OpenCL CPU device on x86-64 (checked against the CPU
-        oracle) -- include/raymarch_hip.h rm_set_contract."""
+        """"gfx950-default" (the library default): the results of the reference kernel as ROCm's OpenCL compiler
+        builds it for this GPU with no options; "gfx950-strict" (= "gfx950"): built with -ffp-contract=off and
+        correctly rounded divide/sqrt (each checked bit for bit against that build); "cpu": the results of an
+        OpenCL CPU device on x86-64 (checked against the CPU oracle) -- include/raymarch_hip.h rm_set_contract."""
         check(lib().rm_set_contract(self._h, CONTRACTS[contract]))
 
     def set_seed_cast(self, mode):

@@ -50,7 +50,7 @@ def update_render_option_buffer(buffers, opts):
 
 
 def init_renderer(width, height, vres, iter=1, vname=None, voxels=None, mc_seed=1000, device=0,
-                  contract="gfx950", **args):
+                  contract="gfx950-default", **args):
     """Build the render state: option records, one scatter table per pass, the
     device context with the volume resident in HBM, and the pipeline
     (core.clj:119-148)."""

@@ -106,7 +106,7 @@ struct rm_ctx {
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
-  int contract = RM_CONTRACT_GFX950_STRICT;  // rm_set_contract: RM_CONTRACT_GFX950_STRICT / RM_CONTRACT_GFX950_DEFAULT / RM_CONTRACT_CPU_DEVICE
+  int contract = RM_CONTRACT_GFX950_DEFAULT;  // (library default, ABI 4) rm_set_contract: RM_CONTRACT_GFX950_STRICT / RM_CONTRACT_GFX950_DEFAULT / RM_CONTRACT_CPU_DEVICE
   // records validated by rm_check_device_opts
   std::vector<RmOpts> dev_recs;
   std::vector<unsigned char> dev_same;  // record i == record i-1 except .time
@@ -405,7 +405,7 @@ extern "C" {
 int rm_host_fail_(int code, const char* msg) { return fail(code, "%s", msg); }
 
 const char* rm_last_error(void) { return g_err; }
-int rm_abi_version(void) { return 3; }  // 3: rm_ctx defaults to RM_CONTRACT_GFX950
+int rm_abi_version(void) { return 4; }  // 3: rm_ctx defaults to RM_CONTRACT_GFX950 (strict); 4: to RM_CONTRACT_GFX950_DEFAULT
 
 int rm_device_count(void) {
   int n = 0;

@@ -156,7 +156,7 @@ class FrameRenderer:
             # caller's stream may share one with them (two slots on one queue do not overlap).
             stream = torch.cuda.current_stream(dev) if nslots == 1 else torch.cuda.Stream(dev)
             slot = _Slot(torch, _native, dev, stream, self.tpp, self.n, root, want_pixels, want_argb, world)
-            if contract:  # None: _native.DEFAULT_CONTRACT, else the library default (RM_CONTRACT_GFX950)
+            if contract:  # None: _native.DEFAULT_CONTRACT, else the library default (RM_CONTRACT_GFX950_DEFAULT)
                 slot.ctx.set_contract(contract)
             if i == 0 or not self.shared_tables:
                 slot.ctx.set_volume_device(self.d_vox.data_ptr(), vres)
@@ -165,6 +165,7 @@ class FrameRenderer:
             slot.ctx.check_device_opts(self.d_opts.data_ptr(), self.iters, self.n, self.width)
             self.slots.append(slot)
         self.frame = 0
+        self._timed_slot = None  # the slot of the last render(timed=True)
         # first slot under the names single-frame callers use
         self.ctx, self.d_tiles = self.slots[0].ctx, self.slots[0].d_tiles
         self.d_pixels, self.d_argb = self.slots[0].d_pixels, self.slots[0].d_argb
@@ -187,10 +188,12 @@ class FrameRenderer:
             mark = lambda i: None  # noqa: E731
         with torch.cuda.stream(slot.stream):
             if self.world == 1:  # the whole frame incl. tonemap is one kernel launch
+                mark(0)
                 slot.ctx.frame_device_full(self.d_opts.data_ptr(), self.d_mc.data_ptr(), self.iters, self.n,
                                            self.width,
                                            slot.d_pixels.data_ptr() if slot.d_pixels is not None else None,
                                            slot.d_argb.data_ptr() if slot.d_argb is not None else None)
+                mark(1); mark(2); mark(3)  # (no gather, no separate resolve)
                 return slot.d_pixels, slot.d_argb
             mark(0)
             if slot.d_argb_tiles is not None:  # ARGB only: every rank tonemaps its tiles, words are exchanged
@@ -222,6 +225,8 @@ class FrameRenderer:
         the rank's own kernels, of the collective as this rank's stream sees it (for the root: until the
         last rank's tiles have arrived, i.e. including the wait for the slowest rank), of the root's resolve."""
         slot = self._timed_slot
+        if slot is None or slot.events is None:
+            raise RuntimeError("last_breakdown(): the last frame was not rendered with render(timed=True)")
         slot.events[3].synchronize()
         e = slot.events
         return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3])

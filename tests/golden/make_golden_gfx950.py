@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Record the outputs of the reference kernel BUILT FOR gfx950 (strict build) -- run on a GPU box.
+"""Record the outputs of the reference kernel BUILT FOR gfx950 (strict and default builds) -- run on a GPU box.
 
-The checker of the device arithmetic contract is oracle/_ref/renderer_gfx950_strict.hsaco: the unmodified
-/root/reference/resources/renderer.cl compiled by oracle/Makefile (`make -C oracle ref_gfx950`:
-clang -x cl -target amdgcn-amd-amdhsa -mcpu=gfx950 -ffp-contract=off
--cl-fp32-correctly-rounded-divide-sqrt, linked by the clang driver against ROCm's own OpenCL
-library).  That file is git-ignored; this script runs it on the GPU exactly as core.clj:76-97 sequences
-the kernels (oracle/ref_gfx950_runner.cpp) and stores DATA ONLY:
+The checkers of the two device arithmetic contracts are oracle/_ref/renderer_gfx950_{strict,default}.hsaco: the
+unmodified /root/reference/resources/renderer.cl compiled by oracle/Makefile (`make -C oracle ref_gfx950`:
+clang -x cl -target amdgcn-amd-amdhsa -mcpu=gfx950, `strict` with -ffp-contract=off
+-cl-fp32-correctly-rounded-divide-sqrt, `default` with no options; linked by the clang driver against ROCm's own
+OpenCL library).  Those files are git-ignored; this script runs them on the GPU exactly as core.clj:76-97 sequences
+the kernels (oracle/ref_gfx950_runner.cpp) and stores DATA ONLY, per build, under tests/golden/gfx950_<build>/:
 
   <scene>.npz    every scene of tests/scenes.py and config 1 at full size: float32 accumulator after all
                  passes, ARGB words, sha256 of the inputs (volume, records, scatter tables, n)
@@ -14,8 +14,8 @@ the kernels (oracle/ref_gfx950_runner.cpp) and stores DATA ONLY:
                  tests/test_gpu_device_contract.py): sha256 of accumulator and ARGB buffer;
   digest_samples.npz  every 997th pixel's bit patterns of those frames
 
-    gpurun -- 'python tests/golden/make_golden_gfx950.py gpurun_out/golden_gfx950'   # then copy into
-    tests/golden/gfx950_strict/ (gpurun only brings gpurun_out/ back)
+    gpurun -- 'python tests/golden/make_golden_gfx950.py gpurun_out/golden_gfx950 [build ...]'   # then copy
+    gpurun_out/golden_gfx950/<build>/ into tests/golden/gfx950_<build>/ (gpurun only brings gpurun_out/ back)
 """
 import json
 import os
@@ -41,13 +41,17 @@ def pass_packed_scene(passes):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else pin.FIXED
-    os.makedirs(out, exist_ok=True)
     oracle.build(ref=False)
-    assert oracle.have_gfx950_ref("strict"), "oracle/_ref/renderer_gfx950_strict.hsaco is not here"
+    for build in (sys.argv[2:] or pin.BUILDS):
+        record(build, os.path.join(sys.argv[1], build) if len(sys.argv) > 1 else pin.fixed_dir(build))
+
+
+def record(build, out):
+    os.makedirs(out, exist_ok=True)
+    assert oracle.have_gfx950_ref(build), f"oracle/_ref/renderer_gfx950_{build}.hsaco is not here"
 
     def full(key, vox, opts, mc, n):
-        px, argb, ms = oracle.gfx950_render_frame(vox, opts, mc, n, build="strict")
+        px, argb, ms = oracle.gfx950_render_frame(vox, opts, mc, n, build=build)
         np.savez_compressed(os.path.join(out, key + ".npz"), pixels=px, argb=argb,
                             inputs=np.array(pin.input_digest(vox, opts, mc, n)), n=np.int32(n))
         print(f"{key:18s} n={n:8d} ref {ms:9.2f} ms  sha {pin.sha(px)[:12]}", flush=True)
@@ -62,7 +66,7 @@ def main():
     digests, samples = {}, {}
 
     def digest(key, vox, opts, mc, n):
-        px, argb, ms = oracle.gfx950_render_frame(vox, opts, mc, n, build="strict")
+        px, argb, ms = oracle.gfx950_render_frame(vox, opts, mc, n, build=build)
         digests[key] = dict(inputs=pin.input_digest(vox, opts, mc, n), n=int(n), pixels_sha=pin.sha(px),
                             argb_sha=pin.sha(argb))
         samples[key] = px.view(np.uint32).reshape(-1, 4)[::pin.SAMPLE_STRIDE].reshape(-1).copy()

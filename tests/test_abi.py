@@ -26,7 +26,7 @@ def test_header_symbols_exported(native):
 
 def test_abi_version_and_error_string(native):
     L = native.lib()
-    assert L.rm_abi_version() == 3
+    assert L.rm_abi_version() == 4
     assert isinstance(L.rm_last_error(), bytes)
 
 

@@ -18,12 +18,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("contract", ["cpu", "gfx950"])
+@pytest.mark.parametrize("contract", ["cpu", "gfx950-strict", "gfx950-default"])
 def test_vox_file_to_png_equals_the_oracle(tmp_path, oracle_mod, contract):
     from PIL import Image
 
-    if contract == "gfx950" and not oracle_mod.have_gfx950_ref("strict"):
-        pytest.skip("oracle/_ref/renderer_gfx950_strict.hsaco not built")
+    build = contract.split("-")[-1]
+    if contract != "cpu" and not oracle_mod.have_gfx950_ref(build):
+        pytest.skip(f"oracle/_ref/renderer_gfx950_{build}.hsaco not built")
     res, w, h, it = 64, 96, 64, 2
     vox = scenes.volume("gyroid", res)
     vio.save_volume(str(tmp_path / "g.vox"), res, vox)
@@ -45,7 +46,7 @@ def test_vox_file_to_png_equals_the_oracle(tmp_path, oracle_mod, contract):
     if contract == "cpu":
         _px, argb = oracle_mod.render_frame(vox, opts, mc, w * h)
     else:
-        _px, argb, _ms = oracle_mod.gfx950_render_frame(vox, opts, mc, w * h, build="strict")
+        _px, argb, _ms = oracle_mod.gfx950_render_frame(vox, opts, mc, w * h, build=build)
     want = np.stack([(argb >> 16) & 255, (argb >> 8) & 255, argb & 255], axis=-1).astype(np.uint8).reshape(h, w, 3)
     assert np.array_equal(got, want)
     assert len(np.unique(got.reshape(-1, 3), axis=0)) > 200  # a real image

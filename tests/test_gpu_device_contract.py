@@ -1,16 +1,18 @@
-"""RM_CONTRACT_GFX950: the kernels reproduce, bit for bit, the pixels of the reference kernel
-itself as ROCm's OpenCL compiler builds it for this chip.
+"""RM_CONTRACT_GFX950_DEFAULT (the library default) and RM_CONTRACT_GFX950_STRICT: the kernels reproduce, bit for
+bit, the pixels of the reference kernel itself as ROCm's OpenCL compiler builds it for this chip -- with no options
+(`default`: clang's OpenCL defaults contract a*b+c inside an expression and lower `/` to 2.5 ulp; this build agrees with
+the reference's OWN -cl-fast-relaxed-math build within 1e-4 on ~all pixels, tests/test_gpu_pin_gfx950.py) and with
+-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt (`strict`).
 
-The checker is oracle/_ref/renderer_gfx950_strict.hsaco -- the UNMODIFIED renderer.cl compiled
-where it lies (oracle/Makefile ref_gfx950: -ffp-contract=off, correctly rounded divide/sqrt) and
-linked by the clang driver against ROCm's own OpenCL built-in library; no stand-in for anything.
-It runs on the GPU through oracle/ref_gfx950_runner.cpp exactly as the reference host sequences
-its kernels (core.clj:76-97).  In this contract the product's built-ins ARE that library's
-functions (csrc/rm_math.hpp), so every float32 of the accumulator and every ARGB word must be
-equal -- whole frames, at every BASELINE configuration's full size.
+The checkers are oracle/_ref/renderer_gfx950_{default,strict}.hsaco -- the UNMODIFIED renderer.cl compiled
+where it lies (oracle/Makefile ref_gfx950) and linked by the clang driver against ROCm's own OpenCL built-in
+library; no stand-in for anything.  They run on the GPU through oracle/ref_gfx950_runner.cpp exactly as the
+reference host sequences its kernels (core.clj:76-97).  In these contracts the product's built-ins ARE that
+library's functions (csrc/rm_math.hpp), so every float32 of the accumulator and every ARGB word must be
+equal -- whole frames, at every BASELINE configuration's full size.  Every test below runs once per contract.
 
-Where that code object is absent (a clean clone: oracle/_ref is git-ignored) the same frames are
-checked against its recorded outputs, tests/golden/gfx950_strict/ (tests/gfx950_pin.py): full
+Where a code object is absent (a clean clone: oracle/_ref is git-ignored) the same frames are
+checked against its recorded outputs, tests/golden/gfx950_<build>/ (oracle/pin.py): full
 accumulators for the fixture scenes and config 1, digests + sampled pixels for the large frames.
 With neither, the tests fail -- they never skip on a GPU box."""
 import os
@@ -20,7 +22,7 @@ import numpy as np
 import pytest
 
 import scenes
-from gfx950_pin import pin  # noqa: F401  (fixture: live reference build, else the committed recordings)
+from gfx950_pin import pin, pin_default, pin_each  # noqa: F401  (fixtures: live reference build, else the committed recordings)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,10 +32,10 @@ if ROOT not in sys.path:
 
 @pytest.fixture(scope="module")
 def refs(oracle_mod):
-    """The LIVE reference build, for the tests that render inputs no recording exists for (random frames)."""
-    if not oracle_mod.have_gfx950_ref("strict"):
-        pytest.skip("oracle/_ref/renderer_gfx950_strict.hsaco not built (needs /root/reference: build container); "
-                    "the recorded frames of tests/golden/gfx950_strict/ are checked by the other tests of this file")
+    """The LIVE reference builds, for the tests that render inputs no recording exists for (random frames)."""
+    if not (oracle_mod.have_gfx950_ref("strict") and oracle_mod.have_gfx950_ref("default")):
+        pytest.skip("oracle/_ref/renderer_gfx950_{strict,default}.hsaco not built (needs /root/reference: build container); "
+                    "the recorded frames of tests/golden/gfx950_*/ are checked by the other tests of this file")
     return oracle_mod
 
 
@@ -42,14 +44,15 @@ def _differing(a, b):
 
 
 @pytest.mark.parametrize("name", list(scenes.SCENES))
-def test_fixture_scenes_every_kernel(native, pin, monkeypatch, name):
+def test_fixture_scenes_every_kernel(native, pin_each, monkeypatch, name):
     """Frame kernel (accelerated), single-pass kernels, the frame tiled over 3 ranks inside the
     library, and the plain table-free kernels: all equal to the reference build."""
+    pin, contract = pin_each
     sc = scenes.build(name)
     n = sc["n"]
     want, want_argb = pin.frame(name, sc["vox"], sc["opts"], sc["mc"], n)
     with native.Context(0) as ctx:
-        ctx.set_contract("gfx950")
+        ctx.set_contract(contract)
         ctx.set_volume(sc["vox"], sc["vres"])
         px, argb = ctx.render_frame(sc["opts"], sc["mc"], n)
         assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
@@ -59,73 +62,82 @@ def test_fixture_scenes_every_kernel(native, pin, monkeypatch, name):
         assert _differing(acc, want) == 0
         assert np.array_equal(ctx.tonemap_image(acc, sc["opts"][:544], n=n), want_argb)
     with native.Context([0, 0, 0]) as ctx:
-        ctx.set_contract("gfx950")
+        ctx.set_contract(contract)
         ctx.set_volume(sc["vox"], sc["vres"])
         px, argb = ctx.render_frame(sc["opts"], sc["mc"], n)
         assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
     monkeypatch.setenv("RAYMARCH_NO_ACCEL", "1")
     with native.Context(0) as ctx:
-        ctx.set_contract("gfx950")
+        ctx.set_contract(contract)
         ctx.set_volume(sc["vox"], sc["vres"])
         px, argb = ctx.render_frame(sc["opts"], sc["mc"], n)
         assert _differing(px, want) == 0 and np.array_equal(argb, want_argb)
 
 
 @pytest.mark.parametrize("passes,pack", [(8, "3"), (16, "4"), (12, "4"), (25, "4")])
-def test_pass_packed_wavefronts(native, pin, monkeypatch, passes, pack):
+def test_pass_packed_wavefronts(native, pin_each, monkeypatch, passes, pack):
+    pin, contract = pin_each
     spec = dict(vol="gyroid", vres=64, w=56, h=40, iter=passes, mat="metal", theta=-30, dist=2.2, dof=0.02)
     sc = scenes.build(spec, mc_seed=500)
     monkeypatch.setenv("RAYMARCH_PASS_PACK", pack)
     with native.Context(0) as ctx:
-        ctx.set_contract("gfx950")
+        ctx.set_contract(contract)
         ctx.set_volume(sc["vox"], sc["vres"])
         px, argb = ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
     pin.assert_frame(f"pass_packed_{passes}", sc["vox"], sc["opts"], sc["mc"], sc["n"], px, argb)
 
 
 @pytest.mark.parametrize("config", ["c1", "c2", "c3", "c4", "c5"])
-def test_baseline_configurations_whole_frames(native, pin, config):
+def test_baseline_configurations_whole_frames(native, pin_each, config):
     """Every BASELINE configuration at its full size, the WHOLE frame: the reference kernel renders
     it on this GPU (C2: 16 launches, ~0.25 s; C4: 64 launches over 8.3 M pixels; or its recorded
     output is read: all of config 1, digest + every 997th pixel of configs 2-5), the product renders
     it in one launch; all floats and all ARGB words equal."""
     import bench
 
+    pin, contract = pin_each
     wl = bench.WORKLOADS[config]
     vox, vres, opts, mc = bench.build_inputs(wl)
     n = wl["w"] * wl["h"]
     with native.Context(0) as ctx:
-        ctx.set_contract("gfx950")
+        ctx.set_contract(contract)
         ctx.set_volume(vox, vres)
         px, argb = ctx.render_frame(opts, mc, n)
         ms, launches = ctx.last_frame_timing()
-    print(f"{config}: {n} pixels x {wl['spp']} passes -- this path {ms:.2f} ms, checker: {pin.source()}")
+    print(f"{config} ({contract}): {n} pixels x {wl['spp']} passes -- this path {ms:.2f} ms, checker: {pin.source()}")
     pin.assert_frame(config, vox, opts, mc, n, px, argb)
     assert len(np.unique(px.reshape(-1, 4)[::97, :3])) > 1000  # a real image
 
 
-def test_contract_is_per_context_and_switchable(native, pin, oracle_mod):
-    """The same context renders both contracts; each equals its own checker."""
+def test_contract_is_per_context_and_switchable(native, pin, pin_default, oracle_mod):
+    """The same context renders all three contracts; each equals its own checker; a context that never names a
+    contract renders the `default` build's pixels (ABI 4)."""
     sc = scenes.build("orange_dof_2spp")
     n = sc["n"]
-    want_dev, _ = pin.frame("orange_dof_2spp", sc["vox"], sc["opts"], sc["mc"], n)
+    want_strict, _ = pin.frame("orange_dof_2spp", sc["vox"], sc["opts"], sc["mc"], n)
+    want_def, _ = pin_default.frame("orange_dof_2spp", sc["vox"], sc["opts"], sc["mc"], n)
     want_cpu, _ = oracle_mod.render_frame(sc["vox"], sc["opts"], sc["mc"], n)
+    assert native.DEFAULT_CONTRACT is None and native.lib().rm_abi_version() >= 4
     with native.Context(0) as ctx:
         ctx.set_volume(sc["vox"], sc["vres"])
+        assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_def) == 0
         for _ in range(2):
-            ctx.set_contract("gfx950")
-            assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_dev) == 0
+            ctx.set_contract("gfx950-strict")
+            assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_strict) == 0
             ctx.set_contract("cpu")
             assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_cpu) == 0
-    assert _differing(want_dev, want_cpu) > 0
+            ctx.set_contract("gfx950-default")
+            assert _differing(ctx.render_frame(sc["opts"], sc["mc"], n)[0], want_def) == 0
+    assert _differing(want_strict, want_cpu) > 0 and _differing(want_strict, want_def) > 0
 
 
-def test_randomised_frames_against_the_reference_build(refs):
-    """tools/fuzz_parity.py in the device contract: random volumes, cameras (inside and around),
+@pytest.mark.parametrize("contract", ["gfx950-default", "gfx950-strict"])
+def test_randomised_frames_against_the_reference_build(refs, contract):
+    """tools/fuzz_parity.py in a device contract: random volumes, cameras (inside and around),
     presets, record overrides, pass counts -- the reference kernel on the GPU is the checker."""
     import subprocess
 
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--contract", "gfx950",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--contract", contract,
                         "--cases", "60", "--seed", "3"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -161,7 +173,7 @@ def test_work_item_undefined_under_the_device_arithmetic_only(native, refs, orac
         oracle_mod.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], acc, n=n, undefined_mask=mask)
     assert not mask.any()  # defined everywhere under the CPU device's arithmetic
     with native.Context(0) as ctx:
-        ctx.set_contract("gfx950")
+        ctx.set_contract("gfx950-strict")
         ctx.set_volume(vox, [64, 64, 64])
         px, _ = ctx.render_frame(opts, mc, n, want_argb=False)
         items = np.nonzero((px.view(np.uint32) != want.view(np.uint32)).reshape(-1, 4).any(axis=1))[0]
@@ -176,15 +188,16 @@ def test_work_item_undefined_under_the_device_arithmetic_only(native, refs, orac
         assert oob[7] > 0 and sum(oob[:7]) == 0, oob
 
 
-def test_recorded_frames_equal_the_live_reference_build(pin, oracle_mod):
-    """Where both checkers exist they must agree: the recordings of tests/golden/gfx950_strict/ ARE
-    the outputs of oracle/_ref/renderer_gfx950_strict.hsaco on this chip (every fixture scene in full,
+def test_recorded_frames_equal_the_live_reference_build(pin_each, oracle_mod):
+    """Where both checkers exist they must agree: the recordings of tests/golden/gfx950_<build>/ ARE
+    the outputs of oracle/_ref/renderer_gfx950_<build>.hsaco on this chip (every fixture scene in full,
     the pass-packed frames and config 2 by digest)."""
+    pin, _contract = pin_each
     if not pin.live:
         pytest.skip("no live reference build on this box: the recordings are the checker")
     import gfx950_pin
 
-    fixed = gfx950_pin.Checker(oracle_mod)
+    fixed = gfx950_pin.Checker(oracle_mod, pin.build)
     fixed.live = False
     for name in scenes.SCENES:
         sc = scenes.build(name)
@@ -196,19 +209,19 @@ def test_recorded_frames_equal_the_live_reference_build(pin, oracle_mod):
     wl = bench.WORKLOADS["c2"]
     vox, vres, opts, mc = bench.build_inputs(wl)
     n = wl["w"] * wl["h"]
-    px, argb, _ = oracle_mod.gfx950_render_frame(vox, opts, mc, n, build="strict")
+    px, argb, _ = oracle_mod.gfx950_render_frame(vox, opts, mc, n, build=pin.build)
     fixed.assert_frame("c2", vox, opts, mc, n, px, argb)
 
 
-def test_a_gpu_box_without_any_checker_fails(pin, oracle_mod, monkeypatch, tmp_path):
+def test_a_gpu_box_without_any_checker_fails(oracle_mod, tmp_path):
     """Neither the code object nor a recording: the check must FAIL, not skip."""
     import gfx950_pin
 
-    monkeypatch.setattr(gfx950_pin, "FIXED", str(tmp_path))
-    c = gfx950_pin.Checker(oracle_mod)
-    c.live = False
-    sc = scenes.build("solid_volume")
-    with pytest.raises(pytest.fail.Exception):
-        c.frame("solid_volume", sc["vox"], sc["opts"], sc["mc"], sc["n"])
-    with pytest.raises(pytest.fail.Exception):
-        c.assert_frame("c2", sc["vox"], sc["opts"], sc["mc"], sc["n"], np.zeros(4 * sc["n"], np.float32), None)
+    for build in gfx950_pin.BUILDS:
+        c = gfx950_pin.Checker(oracle_mod, build, fixed=str(tmp_path))
+        c.live = False
+        sc = scenes.build("solid_volume")
+        with pytest.raises(gfx950_pin.CheckerMissing):
+            c.frame("solid_volume", sc["vox"], sc["opts"], sc["mc"], sc["n"])
+        with pytest.raises(gfx950_pin.CheckerMissing):
+            c.assert_frame("c2", sc["vox"], sc["opts"], sc["mc"], sc["n"], np.zeros(4 * sc["n"], np.float32), None)

@@ -12,9 +12,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gfx950_pin import pin  # noqa: E402,F401
+from gfx950_pin import pin_default as pin  # noqa: E402,F401  (the library default contract)
 
-pytestmark = pytest.mark.gpu  # ranks run in the library's default contract (gfx950): checked against the reference build / its recording
+pytestmark = pytest.mark.gpu  # ranks run in the library's default contract (gfx950-default): checked against the `default` reference build / its recording
 
 
 def _free_port():

@@ -6,8 +6,10 @@ travels with the snapshot like every other built file), launched through hipModu
 
 What can and cannot be asserted: the reference source leaves rounding to the OpenCL compiler
 (core.clj:128 builds with :fast-math :enable-mad), and every re-rounding flips hit/miss decisions
-of a few pixels -- the three reference builds disagree with EACH OTHER on ~1-2 % of
-the pixels.  So the tests assert (a) bit-exactness of the HIP path against the CPU oracle in the
+of a few pixels -- the contraction-off build (`strict`) disagrees with the other two on ~1-2 % of
+the pixels per pass, while `default` and `fast` agree with each other within 1e-4 on ~all of them; the product's
+DEFAULT contract is the `default` build bit for bit (last test of this file: >= 99.9 % of config 2's pixels within
+1e-4 of the reference's own `fast` build).  For the CPU-device contract the tests assert (a) bit-exactness of the HIP path against the CPU oracle in the
 GPU cast mode too, (b) BASELINE's metric -- the fraction of pixels within 1e-4 relative -- of
 the HIP path against each reference build, which must be as good as the agreement of the
 reference builds among themselves, and ~100 % on the pixels where those builds agree.
@@ -105,31 +107,37 @@ def test_metric_against_every_reference_build(rendered, refs):
 
 
 def test_config2_full_size_against_the_references_own_build(refs, native):
-    """BASELINE's headline configuration (256^3 gyroid, 1280x720, 16 passes + DOF) at FULL size, the
-    product in its default (device) contract against `fast` = the reference built with ITS OWN options
-    (-cl-fast-relaxed-math -cl-mad-enable, core.clj:128) -- north star's "pixels within 1e-4 of the
-    OpenCL reference".  16 blended passes make a pixel differ as soon as ONE hit/miss decision of one
-    pass flips under a re-rounding, so two builds of the reference itself agree on ~60 % of the pixels
-    only (profiles/r03_pin_gfx950.txt); asserted here: the product is at least as close to `fast` as
-    the closest other build of the reference is, and within 1e-4 on EVERY pixel on which the three
-    reference builds agree among themselves."""
+    """BASELINE's headline configuration (256^3 gyroid, 1280x720, 16 passes + DOF) at FULL size, the product in
+    its DEFAULT contract against `fast` = the reference built with ITS OWN options (-cl-fast-relaxed-math
+    -cl-mad-enable, core.clj:128) -- north star's "pixels within 1e-4 of the OpenCL reference".
+
+    16 blended passes make a pixel differ as soon as ONE hit/miss decision of one pass flips under a re-rounding:
+    the contraction-off build `strict` sits at ~60 % against `fast`.  The `default` build (contraction inside
+    expressions, 2.5-ulp divide) does not: it agrees with `fast` within 1e-4 on ~100 % of the pixels
+    (profiles/r03_pin_gfx950.txt), and the product's default contract IS that build bit for bit.  Asserted:
+      * default contract == `default` build, every float;  strict contract == `strict` build, every float;
+      * default contract within 1e-4 of `fast` on >= 99.9 % of ALL pixels, and at least as close to `fast` as the
+        CLOSEST other build of the reference is."""
     import bench
 
     wl = bench.WORKLOADS["c2"]
     vox, vres, opts, mc = bench.build_inputs(wl)
     n = wl["w"] * wl["h"]
     px = {b: refs.gfx950_render_frame(vox, opts, mc, n, build=b, tonemap=False)[0] for b in refs.GFX950_BUILDS}
-    with native.Context(0, contract="gfx950") as ctx:  # (= the library default; this module's fixture switches unnamed contexts to "cpu")
-        ctx.set_volume(vox, vres)
-        got, _ = ctx.render_frame(opts, mc, n, want_argb=False)
-    stable = (rel(px["fast"], px["strict"]) <= 1e-4) & (rel(px["fast"], px["default"]) <= 1e-4) & \
-             (rel(px["default"], px["strict"]) <= 1e-4)
+    got = {}
+    for contract in ("gfx950-default", "gfx950-strict"):  # (named: this module's fixture switches unnamed contexts to "cpu")
+        with native.Context(0, contract=contract) as ctx:
+            ctx.set_volume(vox, vres)
+            got[contract], _ = ctx.render_frame(opts, mc, n, want_argb=False)
+    assert np.array_equal(got["gfx950-default"].view(np.uint32), px["default"].view(np.uint32))
+    assert np.array_equal(got["gfx950-strict"].view(np.uint32), px["strict"].view(np.uint32))
     among_fast = max((rel(px["fast"], px[b]) <= 1e-4).mean() for b in ("default", "strict"))
-    r = rel(got, px["fast"])
-    frac, frac_stable = float((r <= 1e-4).mean()), float((r[stable] <= 1e-4).mean())
-    print(f"c2 full size: product vs `fast` {100 * frac:.3f} % of {n} pixels within 1e-4 (closest other reference build: "
-          f"{100 * among_fast:.3f} %); stable pixels {100 * stable.mean():.3f} %, product within 1e-4 on {100 * frac_stable:.4f} % of them")
-    assert np.array_equal(got.view(np.uint32), px["strict"].view(np.uint32))  # (and bit-exact against the strict build)
-    assert frac >= min((rel(px["fast"], px[b]) <= 1e-4).mean() for b in ("default", "strict")) - 1e-9
-    assert frac_stable == 1.0
-    assert 0.3 < stable.mean() < 1.0  # the metric is about a real, chaotic frame
+    r = rel(got["gfx950-default"], px["fast"])
+    frac = float((r <= 1e-4).mean())
+    frac_strict = float((rel(got["gfx950-strict"], px["fast"]) <= 1e-4).mean())
+    print(f"c2 full size: default contract vs `fast` {100 * frac:.4f} % of {n} pixels within 1e-4, {100 * float((r == 0).mean()):.2f} % "
+          f"bit-equal, max rel {r.max():.2e} (closest other reference build: {100 * among_fast:.4f} %); strict contract vs `fast` "
+          f"{100 * frac_strict:.3f} %")
+    assert frac >= 0.999
+    assert frac >= among_fast - 1e-9
+    assert len(np.unique(got["gfx950-default"].reshape(-1, 4)[::97, :3])) > 1000  # a real, chaotic frame

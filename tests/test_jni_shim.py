@@ -69,7 +69,7 @@ def test_clojure_namespace_keeps_the_reference_entry_points():
 
 @pytest.mark.gpu
 def test_every_entry_point_through_a_stand_in_jnienv(tmp_path, native, oracle_mod):
-    """A JNI caller that never mentions a contract gets the library default, RM_CONTRACT_GFX950:
+    """A JNI caller that never mentions a contract gets the library default, RM_CONTRACT_GFX950_DEFAULT:
     its frames equal the reference kernel built for this chip (live build or its recording)."""
     import gfx950_pin
     import scenes
@@ -95,7 +95,7 @@ def test_every_entry_point_through_a_stand_in_jnienv(tmp_path, native, oracle_mo
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint32)
     px, argb, px1, argb1, checks = np.split(raw, [4 * n, 5 * n, 9 * n, 10 * n])
-    want, want_argb = gfx950_pin.Checker(oracle_mod).frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], n)
+    want, want_argb = gfx950_pin.Checker(oracle_mod, "default").frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], n)
     assert np.array_equal(px, want.view(np.uint32)) and np.array_equal(argb, want_argb)
     assert np.array_equal(px1, want.view(np.uint32)) and np.array_equal(argb1, want_argb)
     assert checks.tolist() == [1] * 9, (checks.tolist(), r.stderr[-1500:])

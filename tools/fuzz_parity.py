@@ -21,9 +21,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--contract", default="cpu", choices=["cpu", "gfx950"],
+    ap.add_argument("--contract", default="cpu", choices=["cpu", "gfx950", "gfx950-strict", "gfx950-default"],
                     help="cpu: kernels in the OpenCL-CPU-device contract against the CPU restatement; gfx950: kernels "
-                         "in the device contract against the reference kernel built for gfx950 (strict build), on the GPU")
+                         "in a device contract against the reference kernel built for gfx950 (strict / default build), on the GPU")
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all cases)")
     ap.add_argument("--passes", default="1,2,4,3,8,16", help="pass counts the cases draw from (default: the list the "
                     "earlier rounds' seeds were logged with; add 25,32 for runs that fill 32 pass slots per wavefront)")
@@ -47,6 +47,7 @@ def main():
     bad = skipped = undefined_dev = 0
     ctx = _native.Context(0)
     ctx.set_contract(args.contract)
+    ref_build = "default" if args.contract == "gfx950-default" else "strict"  # the reference build a device contract is pinned to
     t_start = time.time()
     done = 0
     for case in range(args.cases):
@@ -122,7 +123,7 @@ def main():
         mask = np.zeros(n, np.uint8)
         for i in range(it):
             oracle.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], want, n=n, undefined_mask=mask)
-        if args.contract == "gfx950":
+        if args.contract != "cpu":
             # The checker is the reference kernel itself.  A work-item whose material index leaves
             # the record (undefined in the reference, renderer.cl:394,418) makes that kernel read its
             # private copy of the record out of bounds -- on this chip a memory access fault that
@@ -130,7 +131,7 @@ def main():
             if mask.any():
                 skipped += 1
                 continue
-            want, _, _ = oracle.gfx950_render_frame(vox, opts, mc, n, build="strict", tonemap=False)
+            want, _, _ = oracle.gfx950_render_frame(vox, opts, mc, n, build=ref_build, tonemap=False)
         ctx.set_volume(vox, vres3)
         px, _ = ctx.render_frame(opts, mc, n)
         ok = np.repeat(mask == 0, 4)
@@ -144,7 +145,7 @@ def main():
             if args.dump:
                 np.savez(args.dump, vox=vox, vres=np.array(vres3), opts=np.frombuffer(opts, np.uint8), mc=mc, n=n, w=w,
                          ours=px, want=want, mask=mask)
-        if diff and args.contract == "gfx950":
+        if diff and args.contract != "cpu":
             # A work-item may index the materials outside the record under THIS contract's arithmetic only (a
             # bounce that lands elsewhere): the restatement's mask above cannot know.  The plain algorithm in
             # the device contract counts such lookups; per item = count over items 0..i minus count over 0..i-1.
