@@ -20,6 +20,9 @@
 
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
+#ifdef RM_PROBE_CONST_OPTS  // timing probe (tools/, profiles/r05_experiments.txt): the record of config 2 as a compile-time constant
+#include "_probe_opts.h"
+#endif
 
 
 
@@ -122,6 +125,7 @@ struct FrameArgs {
   const uint32_t* __restrict__ surf32;
   unsigned long long oct_stride;
   const float* __restrict__ sdf;
+  const uint8_t* __restrict__ coarse;  // table layouts 6, 7: block minima of the nine tables
   const float4* __restrict__ mc_all;   // scatter table of the launch's first pass
   const RmOpts* __restrict__ opts_all; // record of the launch's first pass
   const RmOpts* __restrict__ opts0;    // record 0 of the frame (TonemapImage reads its gamma)
@@ -196,9 +200,14 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   for (int c0 = 0; c0 == 0; c0 += 1) {  // (one group: c0 = first pass of the group this wavefront holds = of the launch)
     const int pass = c0 + pl;
     const bool live = pass < a.passes;
+#ifdef RM_PROBE_CONST_OPTS
+    const RmOpts* __restrict__ opts = &kProbeOpts;
+#else
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
+#endif
     rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
     sc.log2res = a.log2res;
+    sc.coarse = a.coarse;
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
@@ -357,29 +366,44 @@ int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 // ---- run-time -> compile-time: ONE switch per template axis, used by every launcher ----
 template <int V> using ic = std::integral_constant<int, V>;
 // the contract of a context (rm_api.hip contract_arith) -> ArithOf index; `cpu` = what 0 / 1 mean for the launcher
-// (the frame kernel is instantiated per seed-cast lowering, the single-pass kernels take it at run time)
-template <class F>
-void with_arith(int arith, bool runtime_cast, F&& fn) {
+// (RUNTIME_CAST: the single-pass kernels take the seed-cast lowering at run time, the frame kernel is instantiated per lowering)
+// (A/B builds: -DRM_ONLY_ARITH=a / -DRM_ONLY_LAYOUT=l instantiate the FRAME kernel for that contract / table layout
+//  alone -- a quarter / a sixth of the compile time; other frames fail with hipErrorInvalidValue)
+template <bool RUNTIME_CAST, class F>
+void with_arith(int arith, F&& fn) {
+#ifdef RM_ONLY_ARITH
+  if constexpr (!RUNTIME_CAST) {
+    if (arith == RM_ONLY_ARITH) fn(ic<RM_ONLY_ARITH>{});
+    return;
+  } else
+#endif
   switch (arith) {
     case 3: fn(ic<3>{}); break;
     case 2: fn(ic<2>{}); break;
-    case 1: if (runtime_cast) fn(ic<4>{}); else fn(ic<1>{}); break;
-    default: if (runtime_cast) fn(ic<4>{}); else fn(ic<0>{}); break;
+    case 1: fn(ic<(RUNTIME_CAST ? 4 : 1)>{}); break;
+    default: fn(ic<(RUNTIME_CAST ? 4 : 0)>{}); break;
   }
 }
 template <class F>
 void with_layout(int layout, F&& fn) {
+#ifdef RM_ONLY_LAYOUT
+  if (layout == RM_ONLY_LAYOUT) fn(ic<RM_ONLY_LAYOUT>{});
+#else
   switch (layout) {
     case 1: fn(ic<1>{}); break;
     case 2: fn(ic<2>{}); break;
     case 3: fn(ic<3>{}); break;
     case 4: fn(ic<4>{}); break;
     case 5: fn(ic<5>{}); break;
+    case 6: fn(ic<6>{}); break;
+    case 7: fn(ic<7>{}); break;
     default: fn(ic<0>{}); break;
   }
+#endif
 }
 // table layout of a volume's derived structures (walk_step); `frame`: layout 5 exists in the frame kernel only
 int layout_of(const rmk::Accel& accel, bool frame) {
+  if (frame && accel.bricked && accel.coarse && (accel.log2res == 9 || accel.log2res == 10)) return accel.log2res == 9 ? 6 : 7;
   if (accel.bricked) return accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1);
   if (frame && accel.log2res == 8 && accel.oct_stride) return 5;
   return accel.log2res ? 2 : 0;
@@ -399,7 +423,10 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
   float4* px4 = reinterpret_cast<float4*>(pixels);
   const dim3 grid(blocks), block(64 * kWavesPerBlock);
   const bool acc = accel.dist && accel.surf && !d_counters;  // (event counts are defined on the plain algorithm)
-  with_arith(arith, true, [&](auto A) {
+#ifdef RM_ONLY_FRAME  // (A/B screens of the frame kernel alone: no single-pass instantiations)
+  return hipErrorInvalidValue;
+#else
+  with_arith<true>(arith, [&](auto A) {
     auto go = [&](auto C, auto T, auto AC, auto L) {
       render_pass_kernel<(decltype(C)::value != 0), (decltype(T)::value != 0), (decltype(AC)::value != 0), decltype(L)::value,
                          decltype(A)::value><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, px4, n, id0, id1,
@@ -409,12 +436,13 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
     if (d_counters) go(ic<1>{}, ic<0>{}, ic<0>{}, ic<0>{});
     else if (!acc) { if (tile_major) go(ic<0>{}, ic<1>{}, ic<0>{}, ic<0>{}); else go(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}); }
     else with_layout(layout_of(accel, false), [&](auto L) {
-      if constexpr (decltype(L)::value != 5) {  // (layout 5: frame kernel only)
+      if constexpr (decltype(L)::value < 5) {  // (layouts 5, 6, 7: frame kernel only)
         if (tile_major) go(ic<0>{}, ic<1>{}, ic<1>{}, L); else go(ic<0>{}, ic<0>{}, ic<1>{}, L);
       }
     });
   });
   return hipGetLastError();
+#endif
 }
 
 // log2 of the passes per wavefront (= per launch) for a run of `passes` records that differ in .time only:
@@ -465,6 +493,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.surf32 = f.accel.surf;
   a.oct_stride = f.accel.oct_stride;
   a.sdf = f.sdf;
+  a.coarse = f.accel.coarse;
   a.mc_all = reinterpret_cast<const float4*>(f.mc_all);
   a.opts_all = f.opts_all;
   a.opts0 = f.opts0;
@@ -489,7 +518,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
     if (f.arith == 1) render_frame_kernel<false, RM_SDF_MINW, true, 0, 1><<<grid, block, 0, st>>>(a);
     else render_frame_kernel<false, RM_SDF_MINW, true, 0, 0><<<grid, block, 0, st>>>(a);
   } else {
-    with_arith(f.arith, false, [&](auto A) {
+    with_arith<false>(f.arith, [&](auto A) {
       if (!acc) render_frame_kernel<false, 3, false, 0, decltype(A)::value><<<grid, block, 0, st>>>(a);
       else with_layout(layout_of(f.accel, true), [&](auto L) {
         render_frame_kernel<true, RM_FRAME_MINW, false, decltype(L)::value, decltype(A)::value><<<grid, block, 0, st>>>(a);
@@ -504,7 +533,7 @@ hipError_t launch_tonemap(hipStream_t st, const float* pixels, const RmOpts* d_o
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  with_arith(arith >= 2 ? arith : 0, false, [&](auto A) {  // (no seeds in TonemapImage: one CPU-device instantiation)
+  with_arith<false>(arith >= 2 ? arith : 0, [&](auto A) {  // (no seeds in TonemapImage: one CPU-device instantiation)
     tonemap_kernel<decltype(A)::value><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(pixels), d_opts, argb, n);
   });
   return hipGetLastError();
@@ -515,7 +544,7 @@ hipError_t launch_resolve(hipStream_t st, const float* tiles, int parts, int til
   if (n <= 0) return hipSuccess;
   int blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  with_arith(arith >= 2 ? arith : 0, false, [&](auto A) {
+  with_arith<false>(arith >= 2 ? arith : 0, [&](auto A) {
     resolve_kernel<decltype(A)::value><<<blocks, 256, 0, st>>>(reinterpret_cast<const float4*>(tiles), parts, tiles_per_part,
                                                                d_opts0, reinterpret_cast<float4*>(pixels), argb, n);
   });
