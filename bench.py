@@ -376,6 +376,14 @@ def main():
             for _ in range(3):
                 hctx.render_frame(opts, mc, n)
             host_ms = (time.perf_counter() - th) / 3 * 1e3
+            # what the reference's own caller does: pageable buffers, only the ARGB image read back (core.clj:91-97)
+            pg_mc = np.ascontiguousarray(mc, dtype=np.float32).reshape(-1).copy()
+            pg_argb = np.zeros(n, np.uint32)
+            hctx.render_frame_into(opts, pg_mc, n, None, pg_argb)
+            th = time.perf_counter()
+            for _ in range(5):
+                hctx.render_frame_into(opts, pg_mc, n, None, pg_argb)
+            pageable_argb_ms = (time.perf_counter() - th) / 5 * 1e3
             # the same with long-lived, page-locked caller buffers (what a JNI caller's direct buffers are)
             h_mc = np.ascontiguousarray(mc, dtype=np.float32).reshape(-1)
             h_px, h_argb = np.zeros(4 * n, np.float32), np.zeros(n, np.uint32)
@@ -395,12 +403,15 @@ def main():
             hctx.close()
             out["host_boundary"] = {"ms_per_frame": round(host_ms, 3),
                                     "Mrays_per_s": round(samples_per_frame / host_ms / 1e3, 2),
+                                    "ms_per_frame_argb_only": round(pageable_argb_ms, 3),
+                                    "Mrays_per_s_argb_only": round(samples_per_frame / pageable_argb_ms / 1e3, 2),
                                     "ms_per_frame_pinned": round(pinned_ms, 3),
                                     "ms_per_frame_pinned_argb_only": round(argb_only_ms, 3),
-                                    "note": "rm_render_frame with host buffers (PCIe-inclusive: 4 MiB of tables up, "
-                                            "18 MB of pixels back); _pinned: the caller's buffers registered with "
-                                            "rm_pin_host_buffer; _argb_only: pinned, pixels_out = NULL -- only the 3.7 MB ARGB image comes back, "
-                                            "which is all the reference's pipeline reads (core.clj:91-97)"}
+                                    "note": "rm_render_frame with host buffers the caller never page-locked (PCIe-inclusive: 4 MiB of "
+                                            "tables up, 18 MB of pixels back); _argb_only: the same pageable buffers, pixels_out = NULL -- "
+                                            "only the 3.7 MB ARGB image comes back, which is all the reference's pipeline reads "
+                                            "(core.clj:91-97): what a JNI caller of the reference's render loop gets; _pinned: the "
+                                            "caller's buffers registered with rm_pin_host_buffer"}
         if world == 1:
             # the other arithmetic contracts, same frame, strictly serial (reported, never `value`)
             out["other_contract"] = []

@@ -25,11 +25,6 @@
 
 #include "rm_kernels.h"
 
-#ifndef RM_COARSE_LOG2
-#define RM_COARSE_LOG2 3  // (= rm_shade.hpp kCoarseLog2: the block edge the frame kernel is compiled for)
-#endif
-#define RM_COARSE_LOG2_HOST RM_COARSE_LOG2
-
 namespace {
 
 struct Dim { int rx, ry, rz; };
@@ -224,28 +219,6 @@ __global__ __launch_bounds__(256) void dist_from_oct_kernel(const uint8_t* __res
   }
 }
 
-// Coarse level over the bricked tables of a cubic power-of-two grid (walk_step LAYOUT 6 / 7): per table and block
-// of (1 << cb)^3 cells the smallest value in the block.  One thread per (block, table); a block of 8^3 cells is four
-// whole 128-byte bricks per 4-cell layer pair, read as bytes.
-__global__ __launch_bounds__(256) void coarse_kernel(const uint8_t* __restrict__ tabs, unsigned sh, unsigned cb,
-                                                     uint8_t* __restrict__ out) {
-  const unsigned cs = sh - cb;
-  const unsigned long long per_table = 1ull << (3u * cs), total = 9ull * per_table;
-  const Dim d{1 << sh, 1 << sh, 1 << sh};
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (unsigned long long)gridDim.x * blockDim.x) {
-    const unsigned long long t = i >> (3u * cs), q = i & (per_table - 1ull);
-    const int bx = (int)(q & ((1u << cs) - 1u)) << cb, by = (int)((q >> cs) & ((1u << cs) - 1u)) << cb, bz = (int)(q >> (2u * cs)) << cb;
-    const uint8_t* __restrict__ tab = tabs + (t << (3u * sh));
-    int m = 255;
-    const int e = 1 << cb;
-    for (int z = 0; z < e; z++)
-      for (int y = 0; y < e; y++)
-        for (int x = 0; x < e; x++) m = min(m, (int)tab[tab_index(d, bx + x, by + y, bz + z, 1)]);
-    out[i] = (uint8_t)m;
-  }
-}
-
 // The benchmark volume on the device (reference generators.clj:18-42 fills it on one
 // JVM thread, minutes for 512^3).  Same formula in binary64; cos/sin come from the
 // device math library, so a voxel whose value sits within an ulp of a threshold may
@@ -325,14 +298,6 @@ hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, i
   }
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
   dist_from_oct_kernel<<<blocks, 256, 0, st>>>(oct, total, d_dist9);
-  return hipGetLastError();
-}
-
-unsigned coarse_log2() { return RM_COARSE_LOG2_HOST; }
-hipError_t build_coarse(hipStream_t st, const uint8_t* d_dist9, unsigned log2res, unsigned cb, uint8_t* d_coarse) {
-  const unsigned long long total = 9ull << (3u * (log2res - cb));
-  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-  coarse_kernel<<<blocks, 256, 0, st>>>(d_dist9, log2res, cb, d_coarse);
   return hipGetLastError();
 }
 

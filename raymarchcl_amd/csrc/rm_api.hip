@@ -70,17 +70,16 @@ struct Volume {
   std::mutex mu;
   int device = 0;
   const uint8_t* d_vox = nullptr;  // owned (vox_buf) or borrowed
-  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf, coarse_buf;
+  DevBuf vox_buf, dist_buf, tmp_buf, surf_buf;
   int rx = 0, ry = 0, rz = 0;
   int accel_iso = -1;              // isoVal the tables were built for, -1 = stale
   unsigned long long oct_stride = 0;
   bool bricked = false;            // dist8 / oct8 stored in 8x4x4-cell bricks (volumes beyond the caches)
-  bool coarse = false;             // coarse_buf holds the block minima of the nine bricked tables (512^3 / 1024^3 grids)
   unsigned long long generation = 0;  // bumped whenever the bytes (may) have changed
   double accel_build_ms = 0.0;     // wall time of the last table build (reported by bench.py)
   ~Volume() {
     (void)hipSetDevice(device);
-    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release(); coarse_buf.release();
+    vox_buf.release(); dist_buf.release(); tmp_buf.release(); surf_buf.release();
   }
 };
 
@@ -105,7 +104,6 @@ struct rm_ctx {
                              // 16 + 9 measured 12 % faster than as 6 x 4 + 1)
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
-  bool coarse_level = true;  // RAYMARCH_COARSE=0: no coarse level over the bricked tables of 512^3 / 1024^3 grids (A/B)
   bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
   int contract = RM_CONTRACT_GFX950_DEFAULT;  // (library default, ABI 4) rm_set_contract: RM_CONTRACT_GFX950_STRICT / RM_CONTRACT_GFX950_DEFAULT / RM_CONTRACT_CPU_DEVICE
@@ -212,17 +210,8 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
       HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin, bricked));
       v.oct_stride = tbytes;
       v.bricked = bricked;
-      // coarse level over bricked tables that miss every cache (walk_step LAYOUT 6 / 7): cubic 512^3 / 1024^3 grids
-      v.coarse = false;
-      if (bricked && c->coarse_level && c->pow2_tables && v.rx == v.ry && v.ry == v.rz && (v.rx == 512 || v.rx == 1024)) {
-        const unsigned k = v.rx == 512 ? 9u : 10u, cb = rmk::coarse_log2();
-        HIP_TRY(v.coarse_buf.reserve((size_t)9 << (3u * (k - cb))));
-        HIP_TRY(rmk::build_coarse(c->stream, lin, k, cb, static_cast<uint8_t*>(v.coarse_buf.p)));
-        v.coarse = true;
-      }
     } else {
       v.bricked = false;
-      v.coarse = false;
       HIP_TRY(v.tmp_buf.reserve(vox));
       HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
                                static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
@@ -248,7 +237,6 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   }
   out->dist = static_cast<const uint8_t*>(v.dist_buf.p);
   out->surf = static_cast<const uint32_t*>(v.surf_buf.p);
-  out->coarse = (v.coarse && out->log2res) ? static_cast<const uint8_t*>(v.coarse_buf.p) : nullptr;
   return RM_OK;
 }
 
@@ -477,8 +465,6 @@ static int create_one(int device_id, rm_ctx** out) {
   if (pw && atoi(pw) >= 0 && atoi(pw) <= 100) c->pack_waste = atoi(pw);
   const char* p2 = getenv("RAYMARCH_POW2");
   if (p2) c->pow2_tables = p2[0] != '0';
-  const char* cl = getenv("RAYMARCH_COARSE");
-  if (cl) c->coarse_level = cl[0] != '0';
   *out = c;
   return RM_OK;
 }

@@ -18,7 +18,6 @@ struct Accel {  // nullptrs = not available: the kernels then run the plain fixe
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
   unsigned long long oct_stride = 0;
   bool bricked = false;             // dist / oct tables in 8x4x4-cell bricks of 128 B (oct_stride = bricked table bytes)
-  const uint8_t* coarse = nullptr;  // bricked tables of the 512^3 / 1024^3 grid: one byte per 8^3-cell block and table = the block's minimum (walk_step LAYOUT 6 / 7, frame kernel)
   unsigned log2res = 0;             // > 0: cubic grid of edge 1 << log2res, tables below 4 GiB: row-major (walk_step LAYOUT 2) or the bricks of the 512^3 grid (LAYOUT 3); 10 with bricks: the 1024^3 grid (LAYOUT 4)
 };
 // bytes of one byte table in the bricked layout
@@ -69,9 +68,6 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
 // them (table 0); no scratch
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                          uint8_t* d_dist9, bool bricked = false);
-// block minima of the nine bricked tables of a cubic grid of edge 1 << log2res: d_coarse[t][(res >> cb)^3] (row-major)
-hipError_t build_coarse(hipStream_t st, const uint8_t* d_dist9, unsigned log2res, unsigned cb, uint8_t* d_coarse);
-unsigned coarse_log2();  // the block edge (log2) the kernels are compiled for
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // quality mode: float field -> one float4 per cell (the cell's xy-face at its layer), rm_accel.hip
 hipError_t launch_sdf_quads(hipStream_t st, const float* d_field, int rx, int ry, int rz, float* d_quads);

@@ -125,7 +125,6 @@ struct FrameArgs {
   const uint32_t* __restrict__ surf32;
   unsigned long long oct_stride;
   const float* __restrict__ sdf;
-  const uint8_t* __restrict__ coarse;  // table layouts 6, 7: block minima of the nine tables
   const float4* __restrict__ mc_all;   // scatter table of the launch's first pass
   const RmOpts* __restrict__ opts_all; // record of the launch's first pass
   const RmOpts* __restrict__ opts0;    // record 0 of the frame (TonemapImage reads its gamma)
@@ -207,7 +206,6 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
 #endif
     rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
     sc.log2res = a.log2res;
-    sc.coarse = a.coarse;
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
@@ -395,15 +393,12 @@ void with_layout(int layout, F&& fn) {
     case 3: fn(ic<3>{}); break;
     case 4: fn(ic<4>{}); break;
     case 5: fn(ic<5>{}); break;
-    case 6: fn(ic<6>{}); break;
-    case 7: fn(ic<7>{}); break;
     default: fn(ic<0>{}); break;
   }
 #endif
 }
 // table layout of a volume's derived structures (walk_step); `frame`: layout 5 exists in the frame kernel only
 int layout_of(const rmk::Accel& accel, bool frame) {
-  if (frame && accel.bricked && accel.coarse && (accel.log2res == 9 || accel.log2res == 10)) return accel.log2res == 9 ? 6 : 7;
   if (accel.bricked) return accel.log2res == 9 ? 3 : (accel.log2res == 10 ? 4 : 1);
   if (frame && accel.log2res == 8 && accel.oct_stride) return 5;
   return accel.log2res ? 2 : 0;
@@ -436,7 +431,7 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
     if (d_counters) go(ic<1>{}, ic<0>{}, ic<0>{}, ic<0>{});
     else if (!acc) { if (tile_major) go(ic<0>{}, ic<1>{}, ic<0>{}, ic<0>{}); else go(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}); }
     else with_layout(layout_of(accel, false), [&](auto L) {
-      if constexpr (decltype(L)::value < 5) {  // (layouts 5, 6, 7: frame kernel only)
+      if constexpr (decltype(L)::value != 5) {  // (layout 5: frame kernel only)
         if (tile_major) go(ic<0>{}, ic<1>{}, ic<1>{}, L); else go(ic<0>{}, ic<0>{}, ic<1>{}, L);
       }
     });
@@ -493,7 +488,6 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.surf32 = f.accel.surf;
   a.oct_stride = f.accel.oct_stride;
   a.sdf = f.sdf;
-  a.coarse = f.accel.coarse;
   a.mc_all = reinterpret_cast<const float4*>(f.mc_all);
   a.opts_all = f.opts_all;
   a.opts0 = f.opts0;

@@ -34,7 +34,6 @@ struct Scene {
   const float* __restrict__ sdf = nullptr;  // quality mode: the distance field, one float4 xy-face per cell (Tracer<.., SDFM = true>)
   int seed_cast_gpu = 0;  // (uint) casts of the seed expressions as a GPU device lowers them (rm_set_seed_cast)
   unsigned log2res = 0;   // LAYOUT 2 (walk_step): edge of the cubic grid = 1 << log2res
-  const uint8_t* __restrict__ coarse = nullptr;  // LAYOUT 6, 7: block minima of the nine tables (rm_accel.hip coarse_kernel)
 };
 
 // ---- leaf routines; `o` points at the option record in device memory ----
@@ -150,31 +149,17 @@ RM_DEV float band_of(int v) { return v < 168 ? (v < 84 ? 1.0f : 2.0f) : 3.0f; } 
 //   4  the same for the 1024^3 grid: its nine tables are 9 GiB, beyond any buffer descriptor (the hardware forms
 //      index * stride in 32 bits), so the byte is fetched by a plain 64-bit address = table number << 30 | brick
 //      offset, guarded by the bounds compare
-//   6, 7  layouts 3 and 4 behind a COARSE LEVEL: one byte per 8^3-cell block and table = the smallest value of the
-//      block (18.9 MB for all nine 1024^3 tables, 2.4 MB at 512^3: cache resident, where the fine tables -- 9 GiB /
-//      1.2 GB -- miss every cache on practically every fetch and move a 128-byte line per byte used).  A sample reads
-//      its block's byte first; a value > 0 is a valid (smaller or equal) table value for every cell of the block, so it
-//      is used as the sample's d -- exact by the same proof, the walk only skips fewer samples when the block minimum
-//      is lower than the cell's own value -- and only a block that HOLDS a 0 (a hit cell for dist8, a cell whose cube
-//      ahead is blocked at once for oct8) makes the lane fetch the cell's own byte.  Frame kernel only.
 constexpr unsigned kLog2Res3 = 9;  // LAYOUT 3: the grid is 512^3
 constexpr unsigned kLog2Res4 = 10; // LAYOUT 4: the grid is 1024^3 (the same bricks behind 64-bit addresses: 9 GiB of tables)
 constexpr unsigned kLog2Res5 = 8;  // LAYOUT 5: layout 2 on the 256^3 grid, edge compiled in
-#ifndef RM_COARSE_LOG2
-#define RM_COARSE_LOG2 3
-#endif
-constexpr unsigned kCoarseLog2 = RM_COARSE_LOG2;  // LAYOUT 6, 7: edge of a coarse block = 8 cells
-constexpr bool has_coarse(int layout) { return layout == 6 || layout == 7; }
-constexpr bool bricks_by_shifts(int layout) { return layout == 3 || layout == 4 || layout == 6 || layout == 7; }
-constexpr bool plain_fetch(int layout) { return layout == 4 || layout == 7; }  // 9 GiB of tables: beyond any buffer descriptor
+constexpr bool bricks_by_shifts(int layout) { return layout == 3 || layout == 4; }
 // grid edge (log2) that a layout has compiled in; 0 = read from the table descriptor at run time
 constexpr unsigned fixed_log2(int layout) {
-  return (layout == 3 || layout == 6) ? kLog2Res3 : ((layout == 4 || layout == 7) ? kLog2Res4 : (layout == 5 ? kLog2Res5 : 0u));
+  return layout == 3 ? kLog2Res3 : (layout == 4 ? kLog2Res4 : (layout == 5 ? kLog2Res5 : 0u));
 }
 struct WalkTab {
   const uint8_t* __restrict__ dist8;   // table 0; tables 1..8 follow at oct_stride
-  __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2, 3, 5, 6: all nine tables as one buffer
-  __amdgpu_buffer_rsrc_t coarse;       // LAYOUT 6, 7: the block minima of all nine tables as one buffer
+  __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2, 3, 5: all nine tables as one buffer
   unsigned res, sh;                    // LAYOUT 2: edge of the grid = 1 << sh
   float fres;
 };
@@ -264,51 +249,6 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
   return 0;
 }
 
-// The walk behind the COARSE LEVEL (LAYOUT 6, 7; see the layout list above): the same samples, the same decisions,
-// two kinds of trips.  A VOID trip reads the byte of the sample's 8^3-cell block -- the smallest table value in the
-// block, cache resident -- and uses it as the sample's d when it is not 0.  A block that holds a 0 holds a hit cell
-// (the zero set of all nine tables is the set of hit cells): the lane then PARKS until no lane of the wavefront has a
-// void trip left, and one SURFACE trip fetches the cell's surf32 word from HBM: its low byte is the voxel value, so
-// `v > isoVal` is the reference's own hit test (renderer.cl:222) and a hit has its normal terms already; a cell that
-// is no hit advances ONE sample (d = 1 is a valid table value for every in-grid cell that is not a hit).  The fine
-// tables -- one 128-byte line from HBM per byte used, on practically every trip of every lane -- are not read at all,
-// and the dependent surf32 fetch that followed every hit is the surface trip itself.
-// Returns 1: hit (*cell_out, *w_out = its surf32 word), 2: the walk ends without a hit.
-template <class M, int LAYOUT>
-RM_DEV int walk_coarse(const WalkTab& tab, const uint32_t* __restrict__ surf, int iso, v3& p, int& steps, v3 delta,
-                       float inv_s, float c0, unsigned tnum, int* cell_out, uint32_t* w_out) {
-  constexpr unsigned sh = fixed_log2(LAYOUT), res = 1u << sh, cs = sh - kCoarseLog2;
-  const unsigned toff = tnum << (3u * cs);
-  for (;;) {
-    unsigned cell;
-    int why;  // 0: void trip done, go on; 2: the walk ends; 3: parked at a block that holds a hit cell
-    do {
-      const int qx = M::cell(p.x), qy = M::cell(p.y), qz = M::cell(p.z);
-      const bool ok = ((((unsigned)qx | (unsigned)qy) | (unsigned)qz) < res) & (steps > 0);  // renderer.cl:219, :221
-      cell = ((((unsigned)qz << sh) | (unsigned)qy) << sh) | (unsigned)qx;
-      const unsigned cat = (((((unsigned)qz >> kCoarseLog2) << cs) | ((unsigned)qy >> kCoarseLog2)) << cs) | ((unsigned)qx >> kCoarseLog2);
-      // (a sample outside the grid reads 0 -- its offset is sent beyond the buffer -- and ends the walk through !ok)
-      const int d = (int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(tab.coarse, ok ? cat + toff : 0xffffffffu, 0, 0);
-      const int j = max((int)__builtin_fmaf((float)d, inv_s, c0), 1);
-      why = !ok ? 2 : (d == 0 ? 3 : (j < steps ? 0 : 2));
-      if (why == 0) {
-        skip_samples(p, delta, j);
-        steps -= j;
-      }
-    } while (why == 0);
-    if (why == 2) return 2;
-    const uint32_t w = surf[cell];
-    if ((int)(w & 0xffu) > iso) {
-      *cell_out = (int)cell;
-      *w_out = w;
-      return 1;
-    }
-    if (steps <= 1) return 2;  // (j = 1 >= steps: no sample left that could hit anything)
-    p = p + delta;
-    steps -= 1;
-  }
-}
-
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
 // come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
 // M: the arithmetic contract (rm_math.hpp) -- MathX86<0> OpenCL CPU device, MathX86<1> the same
@@ -343,12 +283,10 @@ struct Tracer {
     tab_.sh = s.log2res;
     tab_.res = 1u << s.log2res;
     tab_.fres = (float)(1u << s.log2res);
-    if (LAYOUT == 2 || LAYOUT == 3 || LAYOUT == 5 || LAYOUT == 6) {
+    if (LAYOUT == 2 || LAYOUT == 3 || LAYOUT == 5) {
       const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
       tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
     }
-    if (has_coarse(LAYOUT))
-      tab_.coarse = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.coarse), 0, (int)(9u << (3u * (fixed_log2(LAYOUT) - kCoarseLog2))), 0x00020000);
   }
   RM_DEV void set_pass(const float4* table_of_pass, float time_of_pass) {
     mc_ = table_of_pass;
@@ -591,24 +529,19 @@ struct Tracer {
         unsigned long long table_off = 0;  // 64-bit: nine 1024^3 tables span 9 GiB
         if (sc.oct_stride) {
           const unsigned int oct = (delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u);
-          table_off = (LAYOUT == 4 || has_coarse(LAYOUT)) ? (unsigned long long)(oct + 1u) : (oct + 1u) * sc.oct_stride;
+          table_off = LAYOUT == 4 ? (unsigned long long)(oct + 1u) : (oct + 1u) * sc.oct_stride;
         }
         (void)s;
         // the loop holds nothing but the walk: a lane that finds its hit waits for the
         // others and all hits are then evaluated together (inside the loop the compiler
         // runs the hit code once per trip in which any lane finishes)
         int cell = 0, r;
-        uint32_t w = 0;
-        if (has_coarse(LAYOUT)) {
-          r = walk_coarse<M, LAYOUT>(tab_, sc.surf, iso, p, steps, delta, inv_s, c0, (unsigned)table_off, &cell, &w);
-        } else {
-          do {
-            r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off);
-          } while (r == 0);
-          if (r == 1) w = sc.surf[cell];
-        }
+        do {
+          r = walk_step<M, LAYOUT>(o, tab_, p, steps, delta, inv_s, c0, &cell, table_off);
+        } while (r == 0);
         if (cut) *cut = limited & (r != 1);  // ended without a hit, possibly only because of the limit
         if (r == 1) {
+          const uint32_t w = sc.surf[cell];
           nrm = surf_normal<M>(w, smooth);
           if (LAYOUT >= 2) p = p * (1.0f / fres);  // (exact: back to the reference's units)
           const v3 hit = madv(p, ld3(o.voxelBounds2), -ld3(o.voxelBounds));
