@@ -205,7 +205,12 @@ int rm_tonemap_image(rm_ctx* ctx, const float* pixels, const void* opts544, uint
  * (opts_i, mc_i), TonemapImage with opts_0, read back.  pixels_out (n float4)
  * and argb_out (n uint32) may each be NULL.  (Buffers registered with
  * rm_pin_host_buffer move by DMA at PCIe speed; others go through the runtime's
- * pageable staging path: 6.1 vs 5.x ms per frame at BASELINE config 2.) */
+ * pageable staging path.  At BASELINE config 2 a caller that reads back only the ARGB image,
+ * as the reference's pipeline does (core.clj:91-97), pays the kernel + ~0.2 ms either way.)
+ * PERFORMANCE CLIFF: records with aoIter > 7 (more than RM_WAVE_AO_PROBES = 8 AO probes per hit; the
+ * reference's default is aoIter = 5) do not fit the exchange area through which a wavefront shares its
+ * secondary rays: such passes go out one launch per pass through the single-pass kernels (each lane traces its own
+ * probes and shadow rays), about 2-3x the time per pass.  Results are bit-identical either way. */
 int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, int iter, int n,
                     float* pixels_out, uint32_t* argb_out);
 
@@ -293,7 +298,8 @@ int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
 /* Device time of the last frame by device of the context: share_ms[r] = the render kernels of device r's
  * tile partition (r < min(rm_num_devices, max_devices)); *frame_ms = from the start of the root's share to
  * the end of its resolve (multi-device: includes the wait for the slowest device's tiles and the peer
- * copies).  Measurement only; blocks until the frame is done. */
+ * copies).  A device that took no part in the last frame (quality-mode frames and frames through a single device's
+ * entry points run on the root alone) reports 0.  Measurement only; blocks until the frame is done. */
 int rm_last_frame_breakdown(rm_ctx* ctx, float* share_ms, int max_devices, float* frame_ms);
 int rm_last_table_build_ms(rm_ctx* ctx, float* ms);
 

@@ -121,6 +121,7 @@ struct rm_ctx {
   const void* repl_mc = nullptr;
   int repl_iter = 0;
   bool timed = false;
+  int last_frame_world = 1;  // devices whose events belong to the last frame (rm_last_frame_breakdown)
   int launches = 0;
   // rm_pin_host_buffer: caller buffers page-locked for the host-buffer entry points
   std::vector<const void*> host_bufs;
@@ -333,7 +334,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     // A record that asks for more AO probes than a wavefront's exchange area holds results for (8: the
     // reference's default is aoIter = 5 -> 6 probes) goes through the single-pass kernel, one launch per pass
     // (each lane traces its own secondary rays there); the frame kernel carries no second AO path for it.
-    if (!sdf_frame && host_recs[i0].aoIter + 1 > 8) {
+    if (!sdf_frame && host_recs[i0].aoIter + 1 > RM_WAVE_AO_PROBES) {
       rmk::Accel accel;
       int rc = ensure_accel(c, host_recs[i0].isoVal, &accel);
       if (rc) return rc;
@@ -379,6 +380,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->timed = true;
   c->launches = launches;
+  if (!c->parent) c->last_frame_world = 1;  // (frame_multi_device raises it once its peers have taken part)
   return RM_OK;
 }
 
@@ -924,6 +926,7 @@ static int frame_multi_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc
                                 d_argb, n, contract_arith(c, sdf)));
   HIP_TRY(hipEventRecord(c->ev_resolved, c->stream));
   c->resolved_once = true;
+  c->last_frame_world = world;
   return RM_OK;
 }
 
@@ -1005,12 +1008,19 @@ int rm_set_sdf_volume(rm_ctx* c, const float* sdf, int rx, int ry, int rz) {
   if (rx > 4096 || ry > 4096 || rz > 4096 || (unsigned long long)rx * ry * rz >= (1ull << 32))
     return fail(RM_EINVAL, "distance field %dx%dx%d: at most 4096 cells per axis and fewer than 2^32 cells", rx, ry, rz);
   const size_t bytes = (size_t)rx * ry * rz * 4;
+  // what the kernel samples is one float4 per cell (4x the field, built once here); the scalar field is only staged
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t have = free_b + c->sdf_buf.cap + c->sdfq_buf.cap;
+  if (bytes * 5 > have)
+    return fail(RM_EDEVICE, "distance field %dx%dx%d needs %.1f GiB of device memory (20 B per cell while it is built, 16 after), "
+                "%.1f GiB are free", rx, ry, rz, (double)(bytes * 5) / (1 << 30), (double)have / (1 << 30));
   HIP_TRY(c->sdf_buf.reserve(bytes));
   HIP_TRY(hipMemcpyAsync(c->sdf_buf.p, sdf, bytes, hipMemcpyHostToDevice, c->stream));
-  // what the kernel samples: one float4 per cell (4x the field; built once here)
   HIP_TRY(c->sdfq_buf.reserve(bytes * 4));
   HIP_TRY(rmk::launch_sdf_quads(c->stream, static_cast<const float*>(c->sdf_buf.p), rx, ry, rz, static_cast<float*>(c->sdfq_buf.p)));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->sdf_buf.release();  // nothing reads the scalar field after the quads are built
   c->sdf_rx = rx; c->sdf_ry = ry; c->sdf_rz = rz;
   return RM_OK;
 }
@@ -1186,7 +1196,8 @@ int rm_last_frame_breakdown(rm_ctx* c, float* share_ms, int max_devices, float* 
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!c->timed) return fail(RM_ESTATE, "no frame has been rendered");
-  const int world = 1 + (int)c->peers.size();
+  // (devices that took part in the LAST frame: a quality-mode frame or an empty one runs on the root alone)
+  const int world = c->last_frame_world;
   if (world > 1 && !c->resolved_once) return fail(RM_ESTATE, "no multi-device frame has been rendered");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventSynchronize(world > 1 ? c->ev_resolved : c->ev1));
@@ -1198,6 +1209,7 @@ int rm_last_frame_breakdown(rm_ctx* c, float* share_ms, int max_devices, float* 
     HIP_TRY(hipEventElapsedTime(&t, d->ev0, d->ev1));
     if (share_ms) share_ms[r] = t;
   }
+  for (int r = world; share_ms && r < 1 + (int)c->peers.size() && r < max_devices; r++) share_ms[r] = 0.f;  // took no part
   HIP_TRY(hipSetDevice(c->device));
   if (frame_ms) {
     float t = 0.f;

@@ -913,7 +913,8 @@ struct Tracer {
   // ballots), which is what lets idle lanes take part.
   // =====================================================================================
   static constexpr int kWaveLdsIn = 9;    // posted inputs per lane
-  static constexpr int kWaveLdsRes = 8;   // results per lane (AO probes <= 8, lights <= 4)
+  static constexpr int kWaveLdsRes = RM_WAVE_AO_PROBES;   // results per lane (AO probes <= 8, lights <= 4)
+  static_assert(kWaveLdsRes >= 4, "the shadow phase keeps one result per light (numLights <= 4)");
   static constexpr int kWaveLdsFloats = (kWaveLdsIn + kWaveLdsRes + 1) * 64;
   RM_DEV float& lds_in(int f, int lane) { return lds_[f * 64 + lane]; }
   RM_DEV float& lds_res(int f, int lane) { return lds_[(kWaveLdsIn + f) * 64 + lane]; }
@@ -954,10 +955,12 @@ struct Tracer {
   // occlusion() for all lanes of the wavefront at once; `active` lanes own a hit
   RM_DEV float occlusion_wave(bool active, const Sample& s, v3 pos, v3 normal) {
     const RmOpts& o = *sc.o;
-    const int np = o.aoIter + 1;
+    // (aoIter + 1 <= kWaveLdsRes: the host sends frames whose records ask for more probes through the single-pass kernels.
+    //  The clamp keeps a record rewritten in place behind the host's validation from writing past the exchange area:
+    //  such a frame gets too few probes, never corrupted LDS.)
+    const int np = min(o.aoIter + 1, kWaveLdsRes);
     const Deal dl = deal(active);
     if (dl.owners == 0) return 1.0f;
-    // (np <= kWaveLdsRes: the host sends frames whose records ask for more probes through the single-pass kernels)
     const uint32_t seed0 =
         seed_of(M::fuse(s.time, 2671.918f, M::fuse(pos.z, 2945.87f, M::fuse(pos.x, 3183.75f, pos.y * 1831.42f))));
     if (active) {
