@@ -96,7 +96,7 @@
         [rx ry rz] res
         handle     (open-device (get args :devices 1))
         pixels     (* width height)]
-    (when-let [c (get args :contract)] (Native/setContract handle (if (= c :gfx950) 1 0)))
+    (when-let [c (get args :contract)] (Native/setContract handle (case c :gfx950-default 2 (:gfx950 :gfx950-strict) 1 :cpu 0)))
     (Native/setVolume handle voxels rx ry rz)
     (let [mc (scatter-tables iter)
           q  (direct (* 4 pixels))]

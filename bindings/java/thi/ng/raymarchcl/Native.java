@@ -27,7 +27,9 @@ public final class Native {
                                          ByteBuffer pixelsOut, ByteBuffer argbOut);
     public static native float lastFrameMillis(long handle);
     public static native int makeScatterTable(long seed, ByteBuffer out);
-    /** 0: the results of an OpenCL CPU device (default); 1: of the reference kernel built for this GPU. */
+    /** Whose results the kernels reproduce bit for bit (rm_set_contract): 2 = the reference kernel as ROCm's OpenCL compiler
+     *  builds it for this GPU with no options (the library default), 1 = the same built with -ffp-contract=off and
+     *  correctly rounded divide/sqrt, 0 = an OpenCL CPU device on x86-64. */
     public static native int setContract(long handle, int contract);
     /** Header of a .vox file (io.clj:9-33): out3 receives rx, ry, rz (3 ints). */
     public static native int voxInfo(String path, ByteBuffer out3);

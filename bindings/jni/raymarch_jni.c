@@ -150,8 +150,9 @@ JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_makeScatterTable(JNIEnv* en
   return check(env, rm_make_scatter_table((uint64_t)seed, p));
 }
 
-/* whose results the kernels reproduce: 0 = an OpenCL CPU device (default), 1 = the reference
- * kernel as ROCm's OpenCL compiler builds it for this GPU (rm_set_contract) */
+/* whose results the kernels reproduce (rm_set_contract): 2 = the reference kernel as ROCm's OpenCL compiler builds it for
+ * this GPU with no options (the library default), 1 = built with -ffp-contract=off and correctly rounded divide/sqrt,
+ * 0 = an OpenCL CPU device */
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_setContract(JNIEnv* env, jclass c, jlong h, jint contract) {
   (void)c;
   return check(env, rm_set_contract(CTX(h), contract));

@@ -213,6 +213,7 @@ int main(int argc, char** argv) {
   /* the arithmetic contract through the shim: accepted values, a bad value raises */
   g_throws = 0;
   checks[8] = Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 1) == 0 &&
+              Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 2) == 0 &&
               Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 0) == 0 && g_throws == 0;
   Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 7);
   checks[8] = checks[8] && g_throws == 1;

@@ -13,8 +13,10 @@ This tool (GPU box) runs them through oracle/ref_gfx950_runner.cpp exactly as th
 does (RenderImage per pass on a zeroed accumulator, core.clj:76-97) and reports BASELINE.json's
 parity metric -- fraction of pixels whose r,g,b all lie within 1e-4 relative -- for
 
-    HIP gfx950     the product in the DEVICE contract (rm_set_contract RM_CONTRACT_GFX950): built-ins =
-                   ROCm's OpenCL library, casts as gfx950 lowers them -- bit-exact with `strict`
+    HIP default    the product in its DEFAULT contract (RM_CONTRACT_GFX950_DEFAULT): built-ins = ROCm's OpenCL
+                   library, casts as gfx950 lowers them, a*b+c fused where clang's OpenCL default fuses it,
+                   2.5-ulp division -- bit-exact with `default`
+    HIP strict     RM_CONTRACT_GFX950_STRICT: the same without contraction, IEEE division -- bit-exact with `strict`
     HIP x86-cast   the product in the CPU-device contract as shipped (the default)
     HIP gpu-cast   the CPU-device contract with rm_set_seed_cast(GPU) (saturating (uint) casts, as
                    gfx950's v_cvt_u32_f32 lowers them in the code objects above)
@@ -97,8 +99,10 @@ def main():
             for mode in ("x86", "gpu"):
                 ctx.set_seed_cast(mode)
                 hip[mode], _ = ctx.render_frame(sc["opts"], sc["mc"], n, want_argb=False)
-            ctx.set_contract("gfx950")
-            hip["dev"], _ = ctx.render_frame(sc["opts"], sc["mc"], n, want_argb=False)
+            ctx.set_contract("gfx950-strict")
+            hip["strict"], _ = ctx.render_frame(sc["opts"], sc["mc"], n, want_argb=False)
+            ctx.set_contract("gfx950-default")
+            hip["default"], _ = ctx.render_frame(sc["opts"], sc["mc"], n, want_argb=False)
         cpu = {}
         t0 = time.time()
         for mode in ("x86", "gpu"):
@@ -120,15 +124,18 @@ def main():
         scratch = np.zeros(4 * n, np.float32)
         for i in range(sc["iter"]):
             oracle.render_image(sc["vox"], sc["mc"][i], sc["opts"][i * 544:(i + 1) * 544], scratch, n=n, undefined_mask=undef)
-        differs = (hip["dev"].view(np.uint32) != ref["strict"].view(np.uint32)).reshape(-1, 4).any(axis=1)
-        out.append(f"  HIP gfx950 contract vs `strict` reference build: {int(differs.sum())} of {n} pixels differ in any bit"
-                   f" ({int((differs & (undef == 0)).sum())} outside the {int(undef.sum())} work-items that are undefined in the reference)")
+        for con in ("default", "strict"):
+            differs = (hip[con].view(np.uint32) != ref[con].view(np.uint32)).reshape(-1, 4).any(axis=1)
+            out.append(f"  HIP {con} contract vs `{con}` reference build: {int(differs.sum())} of {n} pixels differ in any bit"
+                       f" ({int((differs & (undef == 0)).sum())} outside the {int(undef.sum())} work-items that are undefined in the reference)")
         for b in oracle.GFX950_BUILDS:
             out.append(f"  against the `{b}` reference build:")
-            r = rel(hip["dev"], ref[b])
-            out.append(line("HIP gfx950 contract", r, stable))
-            if b == "fast":
-                summary.append((title.split(":")[0], "gfx950 contract", 100.0 * (r <= 1e-4).mean(), 100.0 * (r[stable] <= 1e-4).mean()))
+            for con in ("default", "strict"):
+                r = rel(hip[con], ref[b])
+                out.append(line(f"HIP {con} contract", r, stable))
+                if b == "fast":
+                    summary.append((title.split(":")[0], f"{con} contract" + (" (library default)" if con == "default" else ""),
+                                    100.0 * (r <= 1e-4).mean(), 100.0 * (r[stable] <= 1e-4).mean()))
             for m in ("gpu", "x86"):
                 r = rel(hip[m], ref[b])
                 out.append(line(f"HIP {m}-cast", r, stable))
