@@ -56,6 +56,7 @@ RM_DEV Material material_of(const RmOpts& o, int id, bool* oob = nullptr) {
 // slab test: renderer.cl:153-161
 template <class M>
 RM_DEV float box_entry_of(const RmOpts& o, v3 p, v3 d) {
+  d = M::slab_dir(d);
   const float lox = M::div(o.voxelBoundsMin[0] - p.x, d.x), loy = M::div(o.voxelBoundsMin[1] - p.y, d.y),
               loz = M::div(o.voxelBoundsMin[2] - p.z, d.z);
   const float hix = M::div(o.voxelBoundsMax[0] - p.x, d.x), hiy = M::div(o.voxelBoundsMax[1] - p.y, d.y),
