@@ -282,7 +282,7 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   if (rc) return rc;
   HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, static_cast<const float*>(c->mc_buf.p),
                                   static_cast<const RmOpts*>(c->opts_buf.p), o.resolution[0],
-                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt, c->seed_cast,
+                                  static_cast<float*>(c->pix_buf.p), n, id0, id1, 0, 1, false, d_cnt,
                                   contract_arith(c)));
   HIP_TRY(hipMemcpyAsync(pixels, c->pix_buf.p, pix_bytes, hipMemcpyDeviceToHost, c->stream));
   rm_counters got{};
@@ -341,7 +341,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       if (i0 == 0) HIP_TRY(hipMemsetAsync(out.acc, 0, acc_bytes, c->stream));
       HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0,
                                       resx, out.acc, n, 0, n, out.tile_first, out.tile_stride, !out.row_major, nullptr,
-                                      c->seed_cast, contract_arith(c)));
+                                      contract_arith(c)));
       launches++;
       i0 = i0 + 1;
       if (i0 == iter && out.argb && out.row_major)

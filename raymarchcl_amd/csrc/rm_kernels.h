@@ -27,7 +27,7 @@ hipError_t launch_unbrick(hipStream_t st, const uint8_t* d_bricked, int rx, int 
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* d_vox, Accel accel, const float* d_mc,
                               const RmOpts* d_opts, int resx, float* d_pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters, int seed_cast_gpu = 0, int arith = 0);
+                              Counters* d_counters, int arith = 0);
 // One launch of the frame kernel (rm_kernels.hip render_frame_kernel): `passes` consecutive
 // RenderImage passes (at most 2^pp_log2: what one wavefront holds) over partition (tile_first, tile_stride)
 // of the image, blended in order into `acc`.  pp_log2 > 0: a wavefront holds 2^pp_log2 passes of

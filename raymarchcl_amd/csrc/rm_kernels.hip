@@ -62,16 +62,16 @@ __device__ __forceinline__ int lane_pixel(int tile, int lane, int resx, int tile
 // contiguous 1 KiB store per wave) instead of at the work-item id; used by the
 // device-resident pipeline and the multi-GPU partition, un-permuted by
 // resolve_kernel.
-// ARITH: the arithmetic contract (rmk::ArithOf, rm_math.hpp) -- 4: OpenCL CPU device (seed-cast lowering chosen at
-// run time), 2 / 3: ROCm's OpenCL library on this GPU, strict / default build of the reference
-template <bool COUNT, bool TILE_MAJOR, bool ACCEL, int LAYOUT = 0, int ARITH = 4>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
+// ARITH: the arithmetic contract (rmk::ArithOf, rm_math.hpp)
+template <bool COUNT, bool TILE_MAJOR, bool ACCEL, int LAYOUT = 0, int ARITH = 0>
+// (4 wavefronts per SIMD = 128 VGPRs: every lane of these kernels carries its own secondary rays; compiled for more
+//  wavefronts some instantiations spill SGPRs, which the build's lint refuses)
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void render_pass_kernel(
     const uint8_t* __restrict__ vox, const uint8_t* __restrict__ dist8,
     const uint32_t* __restrict__ surf32, const float4* __restrict__ mc,
     const RmOpts* __restrict__ opts,
     float4* __restrict__ pixels, int n, int id0, int id1, int tile_first, int tile_stride,
-    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0, int seed_cast_gpu = 0,
-    unsigned log2res = 0) {
+    rmk::Counters* __restrict__ counters, unsigned long long oct_stride = 0, unsigned log2res = 0) {
   const int resx = opts->resolution[0];
   const TileGeom g = tile_geom(resx, n);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void render_pass_kernel(
   if (tile >= g.tiles_total) return;
   const int id = lane_pixel((int)tile, lane, resx, g.tiles_x, n, id0, id1);
   rmk::Scene sc{vox, mc, opts, dist8, surf32, oct_stride};
-  sc.seed_cast_gpu = seed_cast_gpu;
   sc.log2res = log2res;
   using M = typename rmk::ArithOf<ARITH>::type;
   rmk::Tracer<COUNT, ACCEL, false, LAYOUT, M> tr(sc);
@@ -342,7 +341,6 @@ __global__ void filter_check_kernel(const float* __restrict__ rays, const RmOpts
                       (rpos.z - o.voxelBoundsMin[2] > m) & (o.voxelBoundsMax[2] - rpos.z > m);
   uint32_t bits = 0;
   if (tr.surely_no_walk(flt, t, g)) bits |= 1u;
-  if (tr.surely_inside(flt, t, g)) bits |= 2u;
   if (t_in >= 0.0f && t_in < g) bits |= 4u;                    // renderer.cl:214: the estimate walks
   if (__float_as_uint(t_in) == 0u) bits |= 8u;                 // the slab test returned exactly +0
   if (inside) bits |= 16u;
@@ -363,14 +361,13 @@ int tiles_total(int resx, int n) { return tile_geom(resx, n).tiles_total; }
 
 // ---- run-time -> compile-time: ONE switch per template axis, used by every launcher ----
 template <int V> using ic = std::integral_constant<int, V>;
-// the contract of a context (rm_api.hip contract_arith) -> ArithOf index; `cpu` = what 0 / 1 mean for the launcher
-// (RUNTIME_CAST: the single-pass kernels take the seed-cast lowering at run time, the frame kernel is instantiated per lowering)
+// the contract of a context (rm_api.hip contract_arith) -> ArithOf index
 // (A/B builds: -DRM_ONLY_ARITH=a / -DRM_ONLY_LAYOUT=l instantiate the FRAME kernel for that contract / table layout
-//  alone -- a quarter / a sixth of the compile time; other frames fail with hipErrorInvalidValue)
-template <bool RUNTIME_CAST, class F>
+//  alone; -DRM_ONLY_FRAME leaves the single-pass kernels out; other launches fail with hipErrorInvalidValue)
+template <bool FRAME, class F>
 void with_arith(int arith, F&& fn) {
 #ifdef RM_ONLY_ARITH
-  if constexpr (!RUNTIME_CAST) {
+  if constexpr (FRAME) {
     if (arith == RM_ONLY_ARITH) fn(ic<RM_ONLY_ARITH>{});
     return;
   } else
@@ -378,8 +375,8 @@ void with_arith(int arith, F&& fn) {
   switch (arith) {
     case 3: fn(ic<3>{}); break;
     case 2: fn(ic<2>{}); break;
-    case 1: fn(ic<(RUNTIME_CAST ? 4 : 1)>{}); break;
-    default: fn(ic<(RUNTIME_CAST ? 4 : 0)>{}); break;
+    case 1: fn(ic<1>{}); break;
+    default: fn(ic<0>{}); break;
   }
 }
 template <class F>
@@ -407,7 +404,7 @@ int layout_of(const rmk::Accel& accel, bool frame) {
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,
-                              Counters* d_counters, int seed_cast_gpu, int arith) {
+                              Counters* d_counters, int arith) {
   const TileGeom g = tile_geom(resx, n);
   if (tile_stride < 1) tile_stride = 1;
   const long long my_tiles =
@@ -421,12 +418,12 @@ hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, c
 #ifdef RM_ONLY_FRAME  // (A/B screens of the frame kernel alone: no single-pass instantiations)
   return hipErrorInvalidValue;
 #else
-  with_arith<true>(arith, [&](auto A) {
+  with_arith<false>(arith, [&](auto A) {
     auto go = [&](auto C, auto T, auto AC, auto L) {
       render_pass_kernel<(decltype(C)::value != 0), (decltype(T)::value != 0), (decltype(AC)::value != 0), decltype(L)::value,
                          decltype(A)::value><<<grid, block, 0, st>>>(vox, accel.dist, accel.surf, mc4, d_opts, px4, n, id0, id1,
                                                                      tile_first, tile_stride, d_counters, accel.oct_stride,
-                                                                     seed_cast_gpu, accel.log2res);
+                                                                     accel.log2res);
     };
     if (d_counters) go(ic<1>{}, ic<0>{}, ic<0>{}, ic<0>{});
     else if (!acc) { if (tile_major) go(ic<0>{}, ic<1>{}, ic<0>{}, ic<0>{}); else go(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}); }
@@ -512,7 +509,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
     if (f.arith == 1) render_frame_kernel<false, RM_SDF_MINW, true, 0, 1><<<grid, block, 0, st>>>(a);
     else render_frame_kernel<false, RM_SDF_MINW, true, 0, 0><<<grid, block, 0, st>>>(a);
   } else {
-    with_arith<false>(f.arith, [&](auto A) {
+    with_arith<true>(f.arith, [&](auto A) {
       if (!acc) render_frame_kernel<false, 3, false, 0, decltype(A)::value><<<grid, block, 0, st>>>(a);
       else with_layout(layout_of(f.accel, true), [&](auto L) {
         render_frame_kernel<true, RM_FRAME_MINW, false, decltype(L)::value, decltype(A)::value><<<grid, block, 0, st>>>(a);

@@ -11,8 +11,7 @@
 //                  rounded via binary64 -- rm_detmath.hpp), (int)/(uint) casts as x86-64 lowers
 //                  them.  Checked bit for bit against the CPU oracle (oracle/rm_restate.c, itself
 //                  bit-identical to the unmodified renderer.cl compiled for x86-64).
-//                  CAST = 1: the same arithmetic with the GPU lowering of the (uint) seed casts;
-//                  CAST = 2: cast lowering chosen at run time (single-pass parity kernels).
+//                  CAST = 1: the same arithmetic with the GPU lowering of the (uint) seed casts.
 //
 //   MathOcl        "this GPU": the built-ins ARE the functions of ROCm's OpenCL built-in library
 //                  (/opt/rocm/amdgcn/bitcode/opencl.bc -> ocml / ockl), linked into this code
@@ -97,11 +96,7 @@ struct MathX86 {
   RM_DEV static float pow(float x, float y) { return rmd::pow_det(x, y); }
   RM_DEV static int to_int(float x) { return rmd::f2i(x); }  // (int)x
   // (uint)x of a seed expression (renderer.cl:267, 334, 471, 472)
-  RM_DEV static uint32_t seed(float x, int runtime_gpu) {
-    if (CAST == 0) return rmd::f2u(x);
-    if (CAST == 1) return rmd::f2u_gpu(x);
-    return runtime_gpu ? rmd::f2u_gpu(x) : rmd::f2u(x);
-  }
+  RM_DEV static uint32_t seed(float x) { return CAST == 0 ? rmd::f2u(x) : rmd::f2u_gpu(x); }
   // one component of convert_int3_sat: truncate, saturate, NaN -> 0 (= v_cvt_i32_f32)
   RM_DEV static int cell(float x) { return rmd::convert_int_sat(x); }
   RM_DEV static void cell3(float tx, float ty, float tz, int& qx, int& qy, int& qz) {
@@ -195,7 +190,7 @@ struct MathOclT {
   RM_DEV static float pow(float x, float y) { return ocl_pow(x, y); }
   // (int)x as the reference object does it on this chip: v_cvt_i32_f32 (saturates, NaN -> 0)
   RM_DEV static int to_int(float x) { return rmd::convert_int_sat(x); }
-  RM_DEV static uint32_t seed(float x, int) { return rmd::f2u_gpu(x); }
+  RM_DEV static uint32_t seed(float x) { return rmd::f2u_gpu(x); }
   // convert_int3_sat of the library: max / min / fptosi / two selects per component -- equal to
   // v_cvt_i32_f32 for every input EXCEPT NaN (library: INT_MIN, instruction: 0)
   RM_DEV static void cell3(float tx, float ty, float tz, int& qx, int& qy, int& qz) {
@@ -221,13 +216,11 @@ using MathOclDef = MathOclT<true>;
 // The contract of a context as the kernels are instantiated on it (ARITH): one table, used by every launcher
 //   0  MathX86<0>  OpenCL CPU device                  1  MathX86<1>  the same, GPU lowering of the seed casts
 //   2  MathOcl     this GPU, strict reference build   3  MathOclDef  this GPU, default reference build
-//   4  MathX86<2>  OpenCL CPU device, seed-cast lowering chosen at run time (single-pass parity kernels)
-constexpr int kArithCount = 4;  // 0..3 reach the frame kernel
+constexpr int kArithCount = 4;
 template <int ARITH> struct ArithOf;
 template <> struct ArithOf<0> { using type = MathX86<0>; };
 template <> struct ArithOf<1> { using type = MathX86<1>; };
 template <> struct ArithOf<2> { using type = MathOcl; };
 template <> struct ArithOf<3> { using type = MathOclDef; };
-template <> struct ArithOf<4> { using type = MathX86<2>; };
 
 }  // namespace rmk

@@ -32,7 +32,6 @@ struct Scene {
   const uint32_t* __restrict__ surf;  // rm_accel.hip surf32, or nullptr
   unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
   const float* __restrict__ sdf = nullptr;  // quality mode: the distance field, one float4 xy-face per cell (Tracer<.., SDFM = true>)
-  int seed_cast_gpu = 0;  // (uint) casts of the seed expressions as a GPU device lowers them (rm_set_seed_cast)
   unsigned log2res = 0;   // LAYOUT 2 (walk_step): edge of the cubic grid = 1 << log2res
 };
 
@@ -252,11 +251,9 @@ RM_DEV int walk_step(const RmOpts& o, const WalkTab& tab, v3& p, int& steps, v3 
 
 // SDFM: QUALITY MODE -- not the reference's algorithm: distance estimates
 // come from a trilinearly sampled float field, normals from its gradient, shadows are soft.
-// M: the arithmetic contract (rm_math.hpp) -- MathX86<0> OpenCL CPU device, MathX86<1> the same
-// with the GPU lowering of the seed casts, MathX86<2> cast lowering chosen at run time by
-// Scene::seed_cast_gpu (single-pass parity kernels; the frame kernel is instantiated per mode so
-// that the flag costs its hot code nothing), MathOcl: ROCm's OpenCL library on this GPU
-template <bool COUNT, bool ACCEL = false, bool SDFM = false, int LAYOUT = 0, class M = MathX86<2>>
+// M: the arithmetic contract (rm_math.hpp ArithOf): MathX86<0> OpenCL CPU device, MathX86<1> the same with the GPU lowering
+// of the seed casts, MathOcl / MathOclDef ROCm's OpenCL library on this GPU as the strict / default build of the reference uses it
+template <bool COUNT, bool ACCEL = false, bool SDFM = false, int LAYOUT = 0, class M = MathX86<0>>
 struct Tracer {
   // the reference's built-ins under the contract (unqualified calls below resolve to these)
   RM_DEV static float dot(v3 a, v3 b) { return M::dot(a, b); }
@@ -295,8 +292,8 @@ struct Tracer {
   }
 
   // the (uint) cast of a seed expression (renderer.cl:267, 334, 471, 472): undefined outside
-  // [0, 2^32); x86-64 lowering by default, GPU lowering on request (uniform branch)
-  RM_DEV uint32_t seed_of(float x) { return M::seed(x, sc.seed_cast_gpu); }
+  // [0, 2^32); lowered as the contract's device lowers it
+  RM_DEV uint32_t seed_of(float x) { return M::seed(x); }
   // scatter table lookup: renderer.cl:142-144
   RM_DEV float4 table(uint32_t seed) {
     if (COUNT) cnt.mc_reads++;
@@ -467,8 +464,8 @@ struct Tracer {
   }
 
   // distance estimate: renderer.cl:209-237
-  // known_inside: the caller has established (slab-test filter) that rpos lies inside
-  // the clip box by a margin; the reference's slab test then returns exactly +0.
+  // known_inside: the caller has established that rpos lies inside the clip box by a margin (no caller does since
+  // round 5: the test below decides); the reference's slab test then returns exactly +0.
   // walk_limit: the caller has no use for a hit beyond that many samples (ao_walk_limit);
   // accelerated path only -- the step vector still comes from `steps`.
   RM_DEV void scene_distance(v3 rpos, v3 dir, int steps, bool smooth, float& dist, float& code,
@@ -591,8 +588,10 @@ struct Tracer {
     float past;    // t > past            =>  far0 - t < -m(t): the box is entirely behind
     float before;  // t + 8e-6|t| + g < before  =>  near0 - t > g + m(t): entry farther than the ground term
                    //   (a line that misses the box by a margin gets before = 64: true while t <= 64)
-    float in_lo, in_hi;  // in_lo <= t < in_hi  =>  near0 - t < -m(t) and far0 - t > m(t): inside the box
-    float g_min;  // ... and the ground term must exceed this: slack + the t-proportional part for every t < in_hi
+    // (Rounds 2-4 also kept in_lo / in_hi / g_min -- "t in [in_lo, in_hi) and g > g_min => the position is inside the
+    //  box, the slab test returns +0" -- to skip the six divisions of the slab test.  Three more floats live across
+    //  every walk of the ray: without them the frame kernel spills 5-23 VGPRs fewer and config 2 / 3 / 5 are 3 / 2 /
+    //  1-4 % faster in every contract, round 5; the margin test inside scene_distance still catches those estimates.)
   };
   RM_DEV BoxFilter make_filter(v3 ro, v3 rd) {
     const RmOpts& o = *sc.o;
@@ -616,13 +615,9 @@ struct Tracer {
     // the line misses the box (b < a) by more than m(64): no walk anywhere up to t = 64
     const bool miss = far0 - near0 < -(slack + 6e-4f);
     f.before = miss ? 64.0f : near0 - slack * 1.01f;
-    f.in_lo = fmaxf(near0 + slack, 0.0f) * 1.00002f;
-    f.in_hi = (far0 - slack) * 0.99998f;  // (<= 0: never inside)
-    f.g_min = slack + 8.1e-6f * fmaxf(f.in_hi, 0.0f);
     if (!ok) {
       f.past = __builtin_inff();
       f.before = -__builtin_inff();
-      f.in_hi = -1.0f;
     }
     return f;
   }
@@ -633,11 +628,6 @@ struct Tracer {
     return (g <= 0.0f)                                               // entry distance is >= 0 or -1: never < g
            | (t > f.past)                                            // box entirely behind
            | (__builtin_fmaf(__builtin_fabsf(t), 8e-6f, t) + g < f.before);  // entry farther than the ground term / box missed
-  }
-  // true when the position at distance t is certainly inside the clip box and the ground
-  // term is positive by a margin: the reference's slab test returns exactly +0 < g
-  RM_DEV bool surely_inside(const BoxFilter& f, float t, float g) {
-    return (t >= f.in_lo) & (t < f.in_hi) & (g > f.g_min);
   }
   // distance_only: the caller uses r.distance alone (shadow rays): walks may stop where a hit
   // could no longer change it (walk_limit_for)
@@ -696,7 +686,6 @@ struct Tracer {
       }
       if (why != 1) break;
       float sd;
-      const bool inside = kFilter && surely_inside(flt, dist, g);
       int limit = 0x7fffffff;
       // (`dist` counts in units of |rdir|: the remaining world distance is (maxDist - dist) * |rdir|)
       if (ACCEL && distance_only)
@@ -708,7 +697,7 @@ struct Tracer {
       // is a filtered one or finds its hit close by)
       if (ACCEL && !distance_only) limit = walk_limit_from(g, spu);
       cut_last = false;
-      scene_distance(M::fuse3(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, inside, limit,
+      scene_distance(M::fuse3(rdir, dist, ro), rdir, o.maxVoxelIter, smooth, sd, scode, r.normal, false, limit,
                      &cut_last);
       last_kind = 1;
       if (__builtin_fabsf(sd) <= o.eps || dist >= maxDist) { why = 4; break; }

@@ -2,14 +2,14 @@
 (renderer.cl:153-161) whose result they predict without evaluating it:
 
   * the per-ray slab filter of Tracer::march ("this distance estimate certainly does not walk
-    the volume" / "the position is certainly inside the clip box"), and
+    the volume"; its second half, "the position is certainly inside the clip box", left the product in
+    round 5: three floats fewer per ray were worth more than the slab tests it saved), and
   * the inside-by-a-margin test of the estimate (the slab test returns exactly +0).
 
 rm_selftest_filter evaluates, for arbitrary (origin, direction, t, ground term), the shortcuts
 and the exact test side by side on the device.  A shortcut may be conservative (say nothing) but
 never wrong: over random rays and rays placed within a few ulps of every decision boundary
   filter "no walk"  =>  the exact test does not walk   (not 0 <= t_in < g)
-  filter "inside"   =>  the exact test returns exactly +0, and +0 < g
   margin "inside"   =>  the exact test returns exactly +0."""
 import numpy as np
 import pytest
@@ -73,7 +73,7 @@ def test_filter_and_margin_shortcuts_never_contradict_the_exact_slab_test(native
     from raymarchcl_amd import structs
 
     rng = np.random.default_rng(77)
-    total = said_no_walk = said_inside = margin = walks = 0
+    total = said_no_walk = margin = walks = 0
     with native.Context(0) as ctx:
         for name, rec in _records():
             lo = np.frombuffer(rec, np.float32, 3, offset=structs.FIELD_OFFSETS["voxelBoundsMin"])
@@ -82,15 +82,12 @@ def test_filter_and_margin_shortcuts_never_contradict_the_exact_slab_test(native
                 rays = _rays(rng, lo.astype(np.float64), hi.astype(np.float64), 1 << 18)
                 bits = ctx.selftest_filter(rec, rays)
                 g = rays[:, 7]
-                no_walk, inside, walk, zero, marg = [(bits >> k) & 1 == 1 for k in range(5)]
+                no_walk, _unused, walk, zero, marg = [(bits >> k) & 1 == 1 for k in range(5)]
                 assert not np.any(no_walk & walk), (name, rays[no_walk & walk][:4])
-                assert not np.any(inside & ~zero), (name, rays[inside & ~zero][:4])
-                assert not np.any(inside & ~(g > 0)), (name, rays[inside & ~(g > 0)][:4])
                 assert not np.any(marg & ~zero), (name, rays[marg & ~zero][:4])
                 total += len(bits)
                 said_no_walk += int(no_walk.sum())
-                said_inside += int(inside.sum())
                 margin += int(marg.sum())
                 walks += int(walk.sum())
     # the shortcuts are exercised, not vacuous
-    assert said_no_walk > total // 10 and said_inside > total // 100 and margin > total // 100 and walks > total // 20
+    assert said_no_walk > total // 10 and margin > total // 100 and walks > total // 20
