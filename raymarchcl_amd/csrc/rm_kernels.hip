@@ -20,9 +20,6 @@
 
 #include "rm_kernels.h"
 #include "rm_shade.hpp"
-#ifdef RM_PROBE_CONST_OPTS  // timing probe (tools/, profiles/r05_experiments.txt): the record of config 2 as a compile-time constant
-#include "_probe_opts.h"
-#endif
 
 
 
@@ -198,11 +195,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   for (int c0 = 0; c0 == 0; c0 += 1) {  // (one group: c0 = first pass of the group this wavefront holds = of the launch)
     const int pass = c0 + pl;
     const bool live = pass < a.passes;
-#ifdef RM_PROBE_CONST_OPTS
-    const RmOpts* __restrict__ opts = &kProbeOpts;
-#else
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
-#endif
     rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
     sc.log2res = a.log2res;
     Tr tr(sc);
