@@ -58,3 +58,29 @@ def test_sdf_api_errors(native):
             ctx.set_sdf_volume(np.ones(8, np.float32), (1, 8, 1))
         with pytest.raises(Exception):
             ctx.set_sdf_volume(np.ones(4097 * 4, np.float32), (4097, 2, 2))   # more than 4096 cells on an axis
+
+
+def test_field_can_be_replaced_and_breakdown_names_the_devices_that_took_part(native, oracle_mod):
+    """rm_set_sdf_volume stages the scalar field, builds the float4 faces and releases the staging copy: a second,
+    larger field on the same context renders as exactly as the first.  A quality-mode frame on a multi-device context
+    runs on the root alone: rm_last_frame_breakdown reports 0 for the other devices instead of an earlier frame's times."""
+    import scenes
+
+    w, h, it = 40, 32, 1
+    n = w * h
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=77)])
+    sc = scenes.build("orange_dof_2spp")
+    with native.Context([0, 0]) as ctx:
+        ctx.set_volume(sc["vox"], sc["vres"])
+        ctx.render_frame(sc["opts"], sc["mc"], sc["n"])          # a frame over both devices
+        shares, frame_ms = ctx.last_frame_breakdown()
+        assert len(shares) == 2 and all(s > 0 for s in shares) and frame_ms > 0
+        for vres in ((24, 24, 24), (40, 32, 48)):
+            sdf = gen.make_sdf_volume(vres, "torus")
+            opts = _records(w, h, it, vres, "metal", -45)
+            want, want_argb = oracle_mod.render_sdf_frame(sdf, opts, mc, n)
+            ctx.set_sdf_volume(sdf, vres)
+            px, argb = ctx.render_sdf_frame(opts, mc, n)
+            assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb)
+        shares, frame_ms = ctx.last_frame_breakdown()
+        assert shares[0] > 0 and shares[1] == 0.0 and frame_ms > 0
