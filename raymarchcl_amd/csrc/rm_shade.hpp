@@ -631,8 +631,11 @@ struct Tracer {
   }
   // distance_only: the caller uses r.distance alone (shadow rays): walks may stop where a hit
   // could no longer change it (walk_limit_for)
+  // unit_dir: rdir comes straight out of normalize() (camera rays, light directions): its length is 1 to a few ulps, so
+  // the walk limits -- bounds whose direction of error alone matters -- take 0.9999 for it and the samples per unit
+  // become a launch-uniform number held in a scalar register (reflected directions are not unit vectors: measured there)
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth,
-                    bool distance_only = false) {
+                    bool distance_only = false, bool unit_dir = false) {
     const RmOpts& o = *sc.o;
     if (COUNT) cnt.rays++;
     float dist = o.startDist;
@@ -662,8 +665,11 @@ struct Tracer {
     //        3 = stopped in a filtered turn, 4 = stopped in an estimated turn
     const int turns0 = maxSteps;
     bool cut_last = false;
-    const float dir_len = (ACCEL && !COUNT) ? __builtin_amdgcn_sqrtf(dot(rdir, rdir)) * 0.9999f : 1.0f;
-    const float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
+    const float dir_len = (ACCEL && !COUNT) ? (unit_dir ? 0.9999f : __builtin_amdgcn_sqrtf(dot(rdir, rdir)) * 0.9999f) : 1.0f;
+    float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
+#ifndef RM_NOSCALAR
+    if (ACCEL && !COUNT && unit_dir) spu = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(spu)));
+#endif
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
     for (;;) {
@@ -728,13 +734,14 @@ struct Tracer {
 
   RM_DEV v3 sky(v3 dir) { return sky_of<M>(*sc.o, dir); }
 
-  struct Sample { v3 eye; v3 mcNormal; float px, py; float time; };
+  // lseed: the seed of the light jitter (renderer.cl:267), a function of px, py and time alone: computed once, so that
+  // px and py are dead after the camera ray
+  struct Sample { v3 eye; v3 mcNormal; float px, py; float time; uint32_t lseed; };
 
   // jittered light position: renderer.cl:263-269
   RM_DEV v3 light_at(const Sample& s, int i) {
     const RmOpts& o = *sc.o;
-    const uint32_t seed = seed_of(M::fuse(s.time, 4763.742f, M::fuse(s.px, 1957.0f, s.py * 2173.0f)));
-    const float4 r = table(seed);
+    const float4 r = table(s.lseed);
     return mads(V(r.x, r.y, r.z), o.lightScatter, ld3(o.lightPos[i]));
   }
   RM_DEV v3 reflect(v3 v, v3 n) { return reflect_of<M>(v, n); }
@@ -757,7 +764,7 @@ struct Tracer {
   // renderer.cl:292-301
   RM_DEV float shadow_term(v3 p, v3 ldir, float lmax) {
     Hit h{};
-    march(p, ldir, h, lmax, sc.o->shadowIter, false, true);
+    march(p, ldir, h, lmax, sc.o->shadowIter, false, true, true);
     return M::step(lmax, h.distance);
   }
   RM_DEV float schlick(float r0, float smooth, v3 n, v3 view) { return schlick_of<M>(r0, smooth, n, view); }
@@ -833,7 +840,7 @@ struct Tracer {
   RM_DEV v3 sample_colour(const Sample& s, v3 ro, v3 rdir) {
     const RmOpts& o = *sc.o;
     Hit h{};
-    march(ro, rdir, h, o.maxDist, o.maxIter, true);
+    march(ro, rdir, h, o.maxDist, o.maxIter, true, false, true);
     v3 col;
     if (h.distance >= o.maxDist) {
       col = sky(rdir);
@@ -875,6 +882,7 @@ struct Tracer {
     s.mcNormal = normalize(V(t.x, t.y, t.z));
     s.px = fx + mcPos.z;
     s.py = fy + mcPos.w;
+    s.lseed = seed_of(M::fuse(s.time, 4763.742f, M::fuse(s.px, 1957.0f, s.py * 2173.0f)));
     s.eye = mads(V(s.mcNormal.z, s.mcNormal.x, s.mcNormal.y), o.dof, ld3(o.eyePos));
     return s;
   }
@@ -1045,7 +1053,7 @@ struct Tracer {
             lds_res(light, owner) = soft_shadow_sdf(M::fuse3(ldir, o.shadowBias, opos), ldir, lmax);
           } else {
             Hit h{};
-            march(M::fuse3(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true);
+            march(M::fuse3(ldir, o.shadowBias, opos), ldir, h, lmax, o.shadowIter, false, true, true);
             lds_res(light, owner) = h.distance;
           }
         }
@@ -1063,7 +1071,7 @@ struct Tracer {
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
-      const float4 r = table(seed_of(M::fuse(s.time, 4763.742f, M::fuse(s.px, 1957.0f, s.py * 2173.0f))));
+      const float4 r = table(s.lseed);
       jit = V(r.x, r.y, r.z);
     }
     // Which (hit, light) pairs need their shadow march at all.  A pair whose diffuse and
@@ -1136,7 +1144,7 @@ struct Tracer {
   RM_DEV v3 sample_colour_wave(const Sample& s, v3 ro, v3 rdir, bool live = true) {
     const RmOpts& o = *sc.o;
     Hit h{};
-    if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true);
+    if (live) march(ro, rdir, h, o.maxDist, o.maxIter, true, false, true);
     const bool hit = live && !(h.distance >= o.maxDist);
     v3 norm = V(0.f, 0.f, 0.f);
     float r0 = 0.0f;
