@@ -54,6 +54,8 @@ typedef struct rm_counters {
 } rm_counters;
 
 const char* rm_last_error(void);
+/* 4.  (3 -> 4, round 5: a context that never calls rm_set_contract renders RM_CONTRACT_GFX950_DEFAULT instead of
+ * RM_CONTRACT_GFX950_STRICT; RM_CONTRACT_GFX950_DEFAULT is new; no entry point changed its signature.) */
 int rm_abi_version(void);
 /* number of visible HIP devices (0 when there is none / no driver) */
 int rm_device_count(void);
