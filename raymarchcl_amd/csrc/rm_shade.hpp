@@ -667,9 +667,7 @@ struct Tracer {
     bool cut_last = false;
     const float dir_len = (ACCEL && !COUNT) ? (unit_dir ? 0.9999f : __builtin_amdgcn_sqrtf(dot(rdir, rdir)) * 0.9999f) : 1.0f;
     float spu = (ACCEL && !COUNT) ? samples_per_unit(o.maxVoxelIter, dir_len) : 0.0f;
-#ifndef RM_NOSCALAR
     if (ACCEL && !COUNT && unit_dir) spu = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(spu)));
-#endif
     int why;
     int last_kind = 0;  // 1: the last executed turn took the real estimate
     for (;;) {

@@ -16,11 +16,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 # the bench instantiations: accelerated, 7 waves/SIMD, table layout 5 (row-major tables of the 256^3
-# grid, edge compiled in), arithmetic contract gfx950 (bench default) and cpu -- and layout 2, the same
-# with the edge read at run time (other cubic power-of-two grids)
-KEYS = ["render_frame_kernelILb1ELi7ELb0ELi5ELi2E", "render_frame_kernelILb1ELi7ELb0ELi5ELi0E",
+# grid, edge compiled in), arithmetic contracts gfx950-default (library and bench default, ArithOf index 3),
+# gfx950-strict (2) and cpu (0) -- and layout 2, the same with the edge read at run time (other cubic
+# power-of-two grids)
+KEYS = ["render_frame_kernelILb1ELi7ELb0ELi5ELi3E", "render_frame_kernelILb1ELi7ELb0ELi5ELi2E",
+        "render_frame_kernelILb1ELi7ELb0ELi5ELi0E", "render_frame_kernelILb1ELi7ELb0ELi2ELi3E",
         "render_frame_kernelILb1ELi7ELb0ELi2ELi2E", "render_frame_kernelILb1ELi7ELb0ELi2ELi0E"]
 KEY = KEYS[0]
+# spilled VGPRs: round 5 found the frame time to follow the allocation (70 -> 30 spilled VGPRs = -9 %);
+# the bench instantiation must not drift back (tools/spill_screen.py finds the site when it does)
+SPILL_BUDGET = {KEYS[0]: 36}
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +53,7 @@ def test_spills_stay_out_of_the_inner_loops(frame_kernel_asm, key):
     assert not deep, f"scratch traffic inside depth >= 3 loops: {deep}"
     at2 = hist.get(2, {"load": 0, "store": 0})
     assert at2["load"] + at2["store"] <= 4, f"scratch traffic inside depth-2 loops: {at2}"
-    assert 8000 < n_ins < 12000  # the kernel the profiles describe, not a different shape
+    assert 7000 < n_ins < 12000  # the kernel the profiles describe, not a different shape
 
 
 @pytest.mark.parametrize("key", KEYS)
@@ -63,7 +68,8 @@ def test_launch_resources_of_the_default_kernel(frame_kernel_asm, key):
     assert get("vgpr_count") <= 72          # 7 wavefronts per SIMD
     assert get("agpr_count") == 0
     assert get("group_segment_fixed_size") <= 5851  # 160 KB / 28 wavefronts per CU
-    assert get("private_segment_fixed_size") <= 200
+    assert get("private_segment_fixed_size") <= 128
+    assert get("vgpr_spill_count") <= SPILL_BUDGET.get(key, 48)
     assert get("sgpr_spill_count") == 0     # no v_writelane / v_readlane spill carriers (round 2: 61)
     assert get("wavefront_size") == 64
 
