@@ -94,6 +94,7 @@ struct rm_ctx {
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
+  bool rows_desc = true;     // RAYMARCH_ROW_ORDER=asc: tile rows top to bottom (rounds 2-4); default bottom to top
   int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most.  Default 4 =
                              // 4 pixels x 16 passes, measured best for full groups (64 passes as 4 x 16 / 2 x 32 / 1 x 64:
                              // 136.0 / 137.3 / 140.3 ms) ...
@@ -365,6 +366,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
     f.pp_log2 = pp_log2;
     f.xcd_rows = c->xcd_rows;
+    f.rows_desc = c->rows_desc;
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
     f.arith = contract_arith(c, sdf_frame);
@@ -459,6 +461,8 @@ static int create_one(int device_id, rm_ctx** out) {
   c->use_octants = !(oc && oc[0] == '0');
   const char* xr = getenv("RAYMARCH_XCD_ROWS");
   if (xr) c->xcd_rows = xr[0] != '0';
+  const char* ro = getenv("RAYMARCH_ROW_ORDER");
+  if (ro) c->rows_desc = !(ro[0] == 'a');
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) { c->pass_pack = atoi(pk); c->pass_pack_auto = false; }
   const char* bk = getenv("RAYMARCH_BRICKS");

@@ -44,6 +44,7 @@ struct FrameLaunch {
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
+  bool rows_desc = true;           // with xcd_rows: tile rows dispatched bottom to top (the top rows -- sky -- make the shortest tail)
   // arithmetic contract (rm_math.hpp ArithOf): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
   // the seed casts (rm_set_seed_cast), 2 / 3 = ROCm's OpenCL library on this GPU as the strict / default
   // build of the reference uses it (rm_set_contract).  Every launcher below takes the same number.

@@ -33,7 +33,8 @@ json.dump(j, open(os.path.join(R, "profiles", "r05_pmc_traffic.json"), "w"), ind
 PY
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 for w in c1 c3 c4 c5; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1; done > $OUT/other_workloads.txt
-python tools/part_timing.py --frames-in-flight 2 --reps 30 > $OUT/part_timing.txt 2>&1
+python tools/part_timing.py --frames-in-flight 1 --reps 30 > $OUT/part_timing.txt 2>&1   # blocking shares: what `value` times
+python tools/part_timing.py --frames-in-flight 2 --reps 30 > $OUT/part_timing_2inflight.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/scale_n1_as_driver.json 2>/dev/null  # the command line of the driver's SCALE run at N = 1
 BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/rehearsal_ranks2.json 2>/dev/null
 BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --backend library --steps 5 --warmup 2 > $OUT/rehearsal_library2.json 2>/dev/null
