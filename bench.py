@@ -79,15 +79,18 @@ def build_inputs(wl):
     return vox, (vres,) * 3, opts, mc
 
 
-def source_digest():
-    """Digest of everything the hot kernel is compiled from (sources + flags): identifies the build
-    a PMC measurement belongs to."""
+def source_digest(rocm_path=None):
+    """Digest of everything the hot kernel is compiled from -- the TRACKED kernel sources + the compiler flags with the
+    location of the ROCm tree normalised out: a property of the sources, not of the box (a git-ignored scratch file in
+    csrc/ or another ROCM_PATH does not change it).  Identifies the build a PMC measurement belongs to."""
     import hashlib
 
     from raymarchcl_amd import _native
 
-    h = hashlib.sha256(" ".join(_native.HIPCC_FLAGS).encode())
-    for name in sorted(os.listdir(_native.CSRC)):
+    root = rocm_path if rocm_path is not None else _native.ROCM_PATH
+    flags = [f.replace(root, "$ROCM") if root else f for f in _native.hipcc_flags(rocm_path)]
+    h = hashlib.sha256(" ".join(flags).encode())
+    for name in _native.kernel_source_files():
         h.update(name.encode())
         h.update(open(os.path.join(_native.CSRC, name), "rb").read())
     return h.hexdigest()[:16]
@@ -141,15 +144,17 @@ def main():
                     help="ranks: one process per GPU, torch.distributed (RCCL) gather of the tile accumulators; "
                          "library: ONE process, the frame tiled over N devices inside the C library "
                          "(rm_create_multi: peer copies over xGMI, no RCCL) -- what a JNI caller gets")
-    ap.add_argument("--contract", default="gfx950-default", choices=["cpu", "gfx950-default", "gfx950-strict"],
+    ap.add_argument("--contract", default="gfx950-default", choices=["cpu", "gfx950-default", "gfx950-strict", "gfx950"],
                     help="arithmetic contract of the kernels (include/raymarch_hip.h rm_set_contract): gfx950-default "
                          "(the library default) / gfx950-strict = the results of the reference kernel as ROCm's OpenCL "
                          "compiler builds it for this GPU with no options / with -ffp-contract=off and correctly "
-                         "rounded divide+sqrt (each checked bit for bit against that build on the GPU); cpu = the "
-                         "results of an OpenCL CPU device (checked against the CPU oracle)")
+                         "rounded divide+sqrt (each checked bit for bit against that build on the GPU; gfx950 = alias "
+                         "of gfx950-strict, the name rounds 2-4 used); cpu = the results of an OpenCL CPU device "
+                         "(checked against the CPU oracle).  Rounds <= 4 benchmarked the strict contract by default: "
+                         "compare round-over-round numbers per contract (`other_contract` carries the others)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r06_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -226,8 +231,11 @@ def main():
             dt = float(tt.item())
         return dt
 
-    kernel_ms = []
     elapsed = timed_steps(fr, blocking=True)
+    # Dominant kernel: render_frame_kernel.  The library records HIP events around the launch(es) of every frame on the
+    # stream they run on and keeps the last 32 pairs: read here, AFTER the loop, they are the device times of the very
+    # frames `elapsed` timed (the last min(K, 32) of them), so ms_per_step >= kernel_ms holds by construction.
+    timed_hist = fr.ctx.frame_timing_history(min(args.steps, 32))
     # the same frames enqueued back to back on several streams (an animation loop that does not wait per frame):
     # reported beside the headline, never `value`
     pipelined = None
@@ -241,12 +249,8 @@ def main():
                      "note": "frame PERIOD with successive frames in flight on separate HIP streams (the tail of one "
                              "launch overlaps the head of the next); no frame finishes sooner than ms_per_step of the headline"}
 
-    # Dominant kernel: render_frame_kernel.  HIP events bracket its launch(es) of a frame on the
-    # stream they run on (the slot's stream, handed to the library); measured on extra frames
-    # right after the timed region so the event reads do not perturb it -- strictly one frame at
-    # a time (overlapped frames stretch each other's launch).  The same frames give the serial
-    # wall time per frame: what a caller of the blocking pipeline (core.clj:171) sees.
-    launches = 1
+    # The serial wall time per frame -- what a caller of the blocking pipeline (core.clj:171) sees -- from a few extra
+    # frames with a host clock around each.
     serial = []
     for _ in range(6):
         sync_all()
@@ -255,9 +259,9 @@ def main():
         fr.render()
         sync_all()
         serial.append((time.perf_counter() - ts) * 1e3)
-        ms, launches = fr.ctx.last_frame_timing()
-        kernel_ms.append(ms / launches)
-    pass_ms = float(np.median(kernel_ms))  # average duration of one render-kernel launch
+    launches = timed_hist[-1][1]
+    kernel_ms = [ms / k for ms, k in timed_hist]
+    pass_ms = float(np.mean(kernel_ms))  # average duration of one render-kernel launch over the timed frames
     serial_ms = float(np.median(serial[1:]))
 
     # N > 1: where a frame's time goes on every rank (events on the rank's stream around its share, the
@@ -345,6 +349,8 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": "render_frame_kernel<accel, 7 waves/SIMD>", "kernel_ms": round(pass_ms, 4),
+                "kernel_ms_source": f"HIP events around the launches of the last {len(timed_hist)} of the {args.steps} timed "
+                                    "blocking frames (rm_frame_timing_history, read after the loop): mean",
                 "launches_per_frame": launches,
                 "alg_bytes_per_launch": int(alg_bytes_launch),
                 "alg_bytes_per_sample": round(alg_bytes_frame / samples_per_frame, 1),

@@ -295,6 +295,13 @@ int rm_check_device_opts(rm_ctx* ctx, const void* d_opts, int iter, int n, int w
  * one), measured with HIP events on the stream they ran on (synchronises).
  * launches = number of render kernel launches in that interval. */
 int rm_last_frame_timing(rm_ctx* ctx, float* ms, int* launches);
+/* The same for the last `max_frames` frames of the context (at most 32 are kept), oldest first:
+ * ms[i] / launches[i] (launches may be NULL), *count = how many were written.  The events are
+ * recorded around the launches whether anyone reads them or not, so a caller that times K
+ * blocking frames with its own clock can read the kernels' device time of THOSE frames after
+ * its loop (bench.py: ms_per_step >= roofline.kernel_ms by construction) -- no reference
+ * counterpart (the reference does not time its kernels; core.clj:171 times the pipeline). */
+int rm_frame_timing_history(rm_ctx* ctx, float* ms, int* launches, int max_frames, int* count);
 /* Device time (HIP events) of the last build of the tables derived from the resident volume
  * (dist8 + oct8 + surf32; once per (volume, isoVal), inside the first call that needs them). */
 /* Device time of the last frame by device of the context: share_ms[r] = the render kernels of device r's

@@ -32,10 +32,24 @@ DEVICE_LIBS = ["opencl.bc", "ocml.bc", "ockl.bc", "oclc_daz_opt_off.bc", "oclc_u
 # (the ROCm tree comes from ROCM_PATH / HIPCC like hipcc's own; the code-object version is spelled out so
 #  that it cannot drift away from the oclc_abi_version_600 bitcode named above)
 ROCM_PATH = os.environ.get("ROCM_PATH", "/opt/rocm")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared", "-mcode-object-version=6", "-mllvm", "-disable-machine-sink", "-mllvm", "-disable-machine-licm",
-               "--hip-device-lib-path=" + os.path.join(ROCM_PATH, "amdgcn", "bitcode")] + \
-              ["--hip-device-lib=" + b for b in DEVICE_LIBS]
+
+
+def hipcc_flags(rocm_path=None):
+    """The product's compiler flags for a ROCm tree at rocm_path (default: ROCM_PATH of this process)."""
+    root = ROCM_PATH if rocm_path is None else rocm_path
+    return ["--offload-arch=gfx950", "-O2", "-fno-slp-vectorize", "-std=c++17", "-ffp-contract=off", "-fPIC",
+            "-shared", "-mcode-object-version=6", "-mllvm", "-disable-machine-sink", "-mllvm", "-disable-machine-licm",
+            "--hip-device-lib-path=" + os.path.join(root, "amdgcn", "bitcode")] + \
+           ["--hip-device-lib=" + b for b in DEVICE_LIBS]
+
+
+HIPCC_FLAGS = hipcc_flags()
+
+
+def kernel_source_files():
+    """Names of the files in csrc/ the library is compiled from (what the repository tracks: scratch files, whose names
+    start with `_` and which .gitignore keeps out of the history, are not sources)."""
+    return sorted(f for f in os.listdir(CSRC) if not f.startswith("_") and os.path.isfile(os.path.join(CSRC, f)))
 
 
 def _hipcc():
@@ -54,7 +68,7 @@ EXPORTS = [
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_frame_device_argb", "rm_resolve_device_argb", "rm_last_frame_breakdown",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims", "rm_selftest_filter",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims", "rm_selftest_filter",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
@@ -92,7 +106,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    files = [os.path.join(CSRC, f) for f in kernel_source_files()]
     files.append(os.path.join(HERE, "..", "include", "raymarch_hip.h"))
     files.append(os.path.abspath(__file__))  # the compiler flags live here
     return any(os.path.getmtime(f) > t for f in files if os.path.isfile(f))
@@ -213,6 +227,7 @@ def lib():
     L.rm_resolve_device_argb.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     L.rm_check_device_opts.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_last_frame_timing.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]
+    L.rm_frame_timing_history.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i), _i, ctypes.POINTER(_i)]
     L.rm_selftest_prims.argtypes = [_vp, _i, _vp, _vp, _vp, _i]
     L.rm_selftest_filter.argtypes = [_vp, _vp, _vp, _i, _vp]
     L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
@@ -502,6 +517,14 @@ class Context:
         k = _i()
         check(lib().rm_last_frame_timing(self._h, ctypes.byref(ms), ctypes.byref(k)))
         return float(ms.value), int(k.value)
+
+    def frame_timing_history(self, max_frames=32):
+        """-> [(ms, launches)] of the last frames (oldest first): device time of their render kernels."""
+        ms = (ctypes.c_float * max_frames)()
+        ln = (_i * max_frames)()
+        k = _i()
+        check(lib().rm_frame_timing_history(self._h, ms, ln, max_frames, ctypes.byref(k)))
+        return [(float(ms[i]), int(ln[i])) for i in range(k.value)]
 
     def debug_get_accel(self, iso):
         nvox = int(np.prod(self.vres))

@@ -114,6 +114,12 @@ struct rm_ctx {
   const void* dev_src = nullptr;
   int dev_iter = 0, dev_n = 0, dev_width = 0;
   unsigned long long dev_generation = 0;
+  // ev0 / ev1 bracket the render kernels of a frame; they point into a ring of pairs so that a caller can read the
+  // device times of the last kTimingRing frames AFTER a timed loop (rm_frame_timing_history)
+  static constexpr int kTimingRing = 32;
+  hipEvent_t ev_ring[2 * kTimingRing] = {};
+  int ring_launches[kTimingRing] = {};
+  unsigned long long frame_seq = 0;  // frames rendered through frame_on_device
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_in = nullptr,
              ev_resolved = nullptr;
   bool resolved_once = false;
@@ -317,6 +323,9 @@ struct FrameOut {
 int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx, int iter, int n,
                     const FrameOut& out, const unsigned char* same_as_prev, const RmOpts* host_recs,
                     bool sdf_frame) {
+  const int ring_slot = (int)(c->frame_seq % rm_ctx::kTimingRing);
+  c->ev0 = c->ev_ring[2 * ring_slot];
+  c->ev1 = c->ev_ring[2 * ring_slot + 1];
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int launches = 0, run_end = 0, pp_log2 = 0;
   for (int i0 = 0; i0 < iter;) {
@@ -382,6 +391,8 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   c->timed = true;
   c->launches = launches;
+  c->ring_launches[ring_slot] = launches;
+  c->frame_seq++;
   if (!c->parent) c->last_frame_world = 1;  // (frame_multi_device raises it once its peers have taken part)
   return RM_OK;
 }
@@ -438,8 +449,9 @@ static int create_one(int device_id, rm_ctx** out) {
   if (!c) return fail(RM_EDEVICE, "out of host memory");
   c->device = device_id;
   e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  for (int k = 0; k < 2 * rm_ctx::kTimingRing && e == hipSuccess; k++) e = hipEventCreate(&c->ev_ring[k]);
+  c->ev0 = c->ev_ring[0];
+  c->ev1 = c->ev_ring[1];
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_resolved);  // (timed: rm_last_frame_breakdown)
@@ -532,8 +544,8 @@ void rm_destroy(rm_ctx* c) {
                     &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->sdfq_buf, &c->atile_buf};
   for (DevBuf* b : bufs) b->release();
   c->vol.reset();
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t ev : c->ev_ring)
+    if (ev) (void)hipEventDestroy(ev);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_resolved) (void)hipEventDestroy(c->ev_resolved);
@@ -1193,6 +1205,24 @@ int rm_last_frame_timing(rm_ctx* c, float* ms, int* launches) {
   HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
   if (ms) *ms = t;
   if (launches) *launches = c->launches;
+  return RM_OK;
+}
+
+int rm_frame_timing_history(rm_ctx* c, float* ms, int* launches, int max_frames, int* count) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (max_frames < 0 || (max_frames > 0 && !ms)) return fail(RM_EINVAL, "max_frames = %d, ms = %p", max_frames, (void*)ms);
+  const unsigned long long have = std::min<unsigned long long>(c->frame_seq, (unsigned long long)rm_ctx::kTimingRing);
+  const int k = (int)std::min<unsigned long long>(have, (unsigned long long)max_frames);
+  for (int i = 0; i < k; i++) {  // oldest of the k first
+    const int slot = (int)((c->frame_seq - (unsigned long long)k + (unsigned long long)i) % rm_ctx::kTimingRing);
+    HIP_TRY(hipEventSynchronize(c->ev_ring[2 * slot + 1]));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev_ring[2 * slot], c->ev_ring[2 * slot + 1]));
+    ms[i] = t;
+    if (launches) launches[i] = c->ring_launches[slot];
+  }
+  if (count) *count = k;
   return RM_OK;
 }
 

@@ -187,6 +187,20 @@ def test_frame_renderer_single_gpu(gpu_ctx, config2):
     assert np.array_equal(d_argb.cpu().numpy().view(np.uint32), argb)
     ms, launches = fr.ctx.last_frame_timing()
     assert launches == 1 and ms > 0  # the whole frame, tonemap included, is one kernel launch
+    # the device times of the last frames, readable after a loop (what bench.py's roofline.kernel_ms is made of)
+    import time
+    seen = len(fr.ctx.frame_timing_history(32))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fr.render()
+        torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    hist = fr.ctx.frame_timing_history(32)
+    assert len(hist) == min(32, seen + 5) and hist[-1] == fr.ctx.last_frame_timing()
+    last5 = hist[-5:]
+    assert all(k == 1 and 0 < m < 1e3 for m, k in last5)
+    assert sum(m for m, _ in last5) <= wall_ms  # the kernels ran inside the frames the host clock timed
+    assert len(fr.ctx.frame_timing_history(3)) == 3 and fr.ctx.frame_timing_history(3) == hist[-3:]
     fr.close()
 
 
