@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r06_pmc_traffic.json"))
     args = ap.parse_args()
+    if args.contract == "gfx950":  # the name rounds 2-4 used
+        args.contract = "gfx950-strict"
 
     import torch
     import torch.distributed as dist
@@ -339,7 +341,8 @@ def main():
                        "contract": args.contract + {
                            "cpu": " (OpenCL CPU device semantics; bit-exact vs the CPU oracle)",
                            "gfx950-default": " (ROCm OpenCL on this GPU; bit-exact vs the reference kernel built for gfx950 with no "
-                                             "options, which is within 1e-4 of the reference's own fast-math build on ~all pixels)",
+                                             "options, which is within 1e-4 of the reference's own fast-math build on 100.0000 % of the pixels of every BASELINE configuration c1-c5, "
+                                             "profiles/r06_pin_gfx950.txt)",
                            "gfx950-strict": " (ROCm OpenCL on this GPU; bit-exact vs the reference kernel built for gfx950 with "
                                             "-ffp-contract=off and correctly rounded divide/sqrt)"}[args.contract],
                        "frames_in_flight": 1,

@@ -115,12 +115,13 @@ int rm_set_seed_cast(rm_ctx* ctx, int mode);
  *     five BASELINE configurations as whole frames (tests/test_gpu_device_contract.py).  The reference's OWN build
  *     options are -cl-fast-relaxed-math -cl-mad-enable (core.clj:128): fast-math lets the compiler re-associate, so
  *     no hand-written kernel can promise its bits, but the `default` build -- and therefore this contract --
- *     agrees with that build within 1e-4 relative on 100.0000 % of the pixels of BASELINE's headline frame
- *     (1280x720x16 passes; max 3.2e-7, 87 % bit-equal; tests/test_gpu_pin_gfx950.py, profiles/r05_pin_gfx950.txt).
+ *     agrees with that build within 1e-4 relative on 100.0000 % of the pixels of EVERY BASELINE configuration at
+ *     full size (c1-c5; max 3.5e-7, 85-87 % bit-equal) and of all fixture scenes (tests/test_gpu_pin_gfx950.py against
+ *     the live code object or its recording tests/golden/gfx950_fast/; profiles/r06_pin_gfx950.txt).
  *   RM_CONTRACT_GFX950_STRICT (= RM_CONTRACT_GFX950, the default of ABI 3): the same built with -ffp-contract=off
  *     -cl-fp32-correctly-rounded-divide-sqrt (oracle/_ref/renderer_gfx950_strict.hsaco, tests/golden/gfx950_strict/).
  *     Bit-exact against that build; against the reference's own build only ~60 % of the headline frame's pixels
- *     are within 1e-4 (one flipped hit/miss decision in any of 16 blended passes moves a pixel) -- the
+ *     are within 1e-4 (50 % at c3, 37 % at c5, 9 % at c4: one flipped hit/miss decision in any blended pass moves a pixel) -- the
  *     contraction-off build is the outlier among the reference's builds, which is why it is no longer the default.
  *   RM_CONTRACT_CPU_DEVICE: an OpenCL CPU device on x86-64 (BASELINE config 1's device) -- built-ins
  *     as the OpenCL 1.2 specification defines them operation by operation, x86-64 cast lowering

@@ -15,6 +15,15 @@ Two sources per build, in this order:
             ON the GPU by tests/golden/make_golden_gfx950.py and committed (data only): full float32 accumulators
             + ARGB words for the fixture scenes and config 1, sha256 digests (digests.json) + a sparse sample of
             pixels (digest_samples.npz) for the large frames (configs 2-5, pass-packed frames).
+A third build is recorded the same way but is NOT a bit-exact checker:
+
+  build "fast"     (no contract)               renderer.cl compiled with the reference's OWN options, -cl-fast-relaxed-math
+                                                -cl-mad-enable (core.clj:128).  Fast-math lets the compiler re-associate, so no
+                                                hand-written kernel can promise its bits; it is the YARDSTICK of BASELINE's
+                                                parity metric ("pixels within 1e-4 of the OpenCL reference"): FastReference
+                                                below serves its pixels -- live, or from tests/golden/gfx950_fast/ (full
+                                                frames for the fixtures and config 1, every 997th pixel of configs 2-5).
+
 A clean clone on a GPU box therefore still checks every device-contract frame bit for bit; when neither source
 exists the check raises CheckerMissing (an AssertionError: tests FAIL, they do not skip -- a GPU box without a
 checker is a broken checkout, not a reason to pass).
@@ -29,7 +38,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAMPLE_STRIDE = 997  # pixels kept from a digest-pinned frame (prime: walks through rows and columns)
-BUILDS = ("strict", "default")
+BUILDS = ("strict", "default")  # the bit-exact checkers, one per device contract
+METRIC_BUILD = "fast"           # the reference's own build options: yardstick of the 1e-4 metric (FastReference)
+RECORDED = BUILDS + (METRIC_BUILD,)  # builds whose outputs are committed under tests/golden/gfx950_<build>/
 CONTRACT_OF = {"strict": "gfx950-strict", "default": "gfx950-default"}  # raymarchcl_amd._native.CONTRACTS names
 
 
@@ -106,3 +117,46 @@ class Checker:
         assert sha(px) == d["pixels_sha"], f"{key}: accumulator digest differs from the reference build's"
         if argb is not None:
             assert sha(np.asarray(argb, dtype=np.uint32)) == d["argb_sha"], f"{key}: ARGB digest differs"
+
+
+def rel_err(a, b):
+    """BASELINE's parity metric per pixel: max over r, g, b of |a - b| / max(|a|, |b|, 1e-6); a, b float32 [k, 4] or [4k]."""
+    a = np.asarray(a).reshape(-1, 4)[:, :3].astype(np.float64)
+    b = np.asarray(b).reshape(-1, 4)[:, :3].astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        r = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+    r[np.isnan(a) | np.isnan(b)] = np.inf
+    r[np.isnan(a) & np.isnan(b)] = 0.0
+    return r.max(axis=1)
+
+
+class FastReference:
+    """Pixels of the reference built with its own options (`fast`) for BASELINE's 1e-4 metric: the live code object where
+    oracle/_ref travelled, else the committed recording.  pixels() -> (float32 [k, 4], stride): stride 1 = every pixel of
+    the frame, SAMPLE_STRIDE = every 997th (configs 2-5 from the recordings)."""
+
+    def __init__(self, oracle_mod, fixed=None):
+        self.oracle = oracle_mod
+        self.fixed = fixed or fixed_dir(METRIC_BUILD)
+        self.live = bool(oracle_mod.have_gfx950_ref(METRIC_BUILD)) and os.environ.get("RAYMARCH_PIN_FIXED_ONLY", "0") != "1"
+
+    def source(self):
+        return "live `fast` reference build" if self.live else "committed recordings of the `fast` build"
+
+    def pixels(self, key, vox, opts, mc, n):
+        if self.live:
+            px, _, _ = self.oracle.gfx950_render_frame(vox, opts, mc, n, build=METRIC_BUILD, tonemap=False)
+            return px.reshape(-1, 4), 1
+        path = os.path.join(self.fixed, key + ".npz")
+        if os.path.exists(path):
+            z = np.load(path)
+            assert str(z["inputs"]) == input_digest(vox, opts, mc, n), f"fixture {key} was recorded for other inputs"
+            return z["pixels"].reshape(-1, 4).copy(), 1
+        dj = os.path.join(self.fixed, "digests.json")
+        d = (json.load(open(dj)) if os.path.exists(dj) else {}).get(key)
+        if d is None:
+            raise CheckerMissing(f"no `fast` reference for `{key}`: neither oracle/_ref/renderer_gfx950_fast.hsaco nor a "
+                                 f"recording under {os.path.relpath(self.fixed, ROOT)} exists")
+        assert d["inputs"] == input_digest(vox, opts, mc, n), f"sample of {key} was recorded for other inputs"
+        s = np.load(os.path.join(self.fixed, "digest_samples.npz"))[key]
+        return s.view(np.float32).reshape(-1, 4).copy(), SAMPLE_STRIDE

@@ -2,7 +2,8 @@
 gfx950, else its committed recordings under tests/golden/gfx950_<build>/; with neither a test FAILS)."""
 import pytest
 
-from oracle.pin import BUILDS, CONTRACT_OF, SAMPLE_STRIDE, Checker, CheckerMissing, fixed_dir, input_digest, sha  # noqa: F401
+from oracle.pin import (BUILDS, CONTRACT_OF, METRIC_BUILD, RECORDED, SAMPLE_STRIDE, Checker, CheckerMissing,  # noqa: F401
+                        FastReference, fixed_dir, input_digest, rel_err, sha)
 
 FIXED = fixed_dir("strict")
 
@@ -23,3 +24,9 @@ def pin_default(oracle_mod):
 def pin_each(request, oracle_mod):
     """Both device contracts in turn: (checker, contract name for Context.set_contract)."""
     return Checker(oracle_mod, request.param), CONTRACT_OF[request.param]
+
+
+@pytest.fixture(scope="session")
+def fast_ref(oracle_mod):
+    """The reference built with its own options: yardstick of BASELINE's 1e-4 metric (not a bit-exact checker)."""
+    return FastReference(oracle_mod)

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Record the outputs of the reference kernel BUILT FOR gfx950 (strict and default builds) -- run on a GPU box.
+"""Record the outputs of the reference kernel BUILT FOR gfx950 (strict, default and fast builds) -- run on a GPU box.
 
 The checkers of the two device arithmetic contracts are oracle/_ref/renderer_gfx950_{strict,default}.hsaco: the
 unmodified /root/reference/resources/renderer.cl compiled by oracle/Makefile (`make -C oracle ref_gfx950`:
 clang -x cl -target amdgcn-amd-amdhsa -mcpu=gfx950, `strict` with -ffp-contract=off
 -cl-fp32-correctly-rounded-divide-sqrt, `default` with no options; linked by the clang driver against ROCm's own
-OpenCL library).  Those files are git-ignored; this script runs them on the GPU exactly as core.clj:76-97 sequences
+OpenCL library).  `fast` (-cl-fast-relaxed-math -cl-mad-enable, the reference's own options, core.clj:128) is recorded the
+same way: not a bit-exact checker but the yardstick of BASELINE's 1e-4 metric (oracle/pin.py FastReference).  Those files are git-ignored; this script runs them on the GPU exactly as core.clj:76-97 sequences
 the kernels (oracle/ref_gfx950_runner.cpp) and stores DATA ONLY, per build, under tests/golden/gfx950_<build>/:
 
   <scene>.npz    every scene of tests/scenes.py and config 1 at full size: float32 accumulator after all
@@ -42,7 +43,7 @@ def pass_packed_scene(passes):
 
 def main():
     oracle.build(ref=False)
-    for build in (sys.argv[2:] or pin.BUILDS):
+    for build in (sys.argv[2:] or pin.RECORDED):
         record(build, os.path.join(sys.argv[1], build) if len(sys.argv) > 1 else pin.fixed_dir(build))
 
 

@@ -8,12 +8,13 @@ What can and cannot be asserted: the reference source leaves rounding to the Ope
 (core.clj:128 builds with :fast-math :enable-mad), and every re-rounding flips hit/miss decisions
 of a few pixels -- the contraction-off build (`strict`) disagrees with the other two on ~1-2 % of
 the pixels per pass, while `default` and `fast` agree with each other within 1e-4 on ~all of them; the product's
-DEFAULT contract is the `default` build bit for bit (last test of this file: >= 99.9 % of config 2's pixels within
-1e-4 of the reference's own `fast` build).  For the CPU-device contract the tests assert (a) bit-exactness of the HIP path against the CPU oracle in the
+DEFAULT contract is the `default` build bit for bit (last tests of this file: the fraction of pixels within 1e-4 of the
+reference's own `fast` build for EVERY BASELINE configuration and every fixture scene, against the live code object or
+its committed recording tests/golden/gfx950_fast/).  For the CPU-device contract the tests assert (a) bit-exactness of the HIP path against the CPU oracle in the
 GPU cast mode too, (b) BASELINE's metric -- the fraction of pixels within 1e-4 relative -- of
 the HIP path against each reference build, which must be as good as the agreement of the
 reference builds among themselves, and ~100 % on the pixels where those builds agree.
-Numbers: profiles/r03_pin_gfx950.txt (tools/pin_gfx950.py)."""
+Numbers: profiles/r06_pin_gfx950.txt (tools/pin_gfx950.py; rounds 3-5: r03_/r05_pin_gfx950.txt)."""
 import numpy as np
 import pytest
 
@@ -99,45 +100,78 @@ def test_metric_against_every_reference_build(rendered, refs):
         frac, frac_stable = (r <= 1e-4).mean(), (r[stable] <= 1e-4).mean()
         print(f"{name}: HIP gpu-cast vs `{b}`: {100 * frac:.3f} % within 1e-4 ({100 * frac_stable:.3f} % of the stable "
               f"pixels; reference builds among themselves: {100 * among:.3f} %)")
-        # measured (profiles/r03_pin_gfx950.txt): 96.6-98 % of all pixels, 97.4-99 % of the stable ones
+        # measured (profiles/r03_pin_gfx950.txt, unchanged since): 96.6-98 % of all pixels, 97.4-99 % of the stable ones
         # -- the x86-strict arithmetic of this path (unfused mad, IEEE normalize, its own exp/pow)
         # against ocml's; the reference builds agree among themselves on 97.3-99.2 %
         assert frac >= 0.95, (b, frac, among)
         assert frac_stable >= 0.96, (b, frac_stable)
 
 
-def test_config2_full_size_against_the_references_own_build(refs, native):
-    """BASELINE's headline configuration (256^3 gyroid, 1280x720, 16 passes + DOF) at FULL size, the product in
-    its DEFAULT contract against `fast` = the reference built with ITS OWN options (-cl-fast-relaxed-math
-    -cl-mad-enable, core.clj:128) -- north star's "pixels within 1e-4 of the OpenCL reference".
+# ---- north star: "pixels within 1e-4 of the OpenCL reference" = of the reference built with ITS OWN options ----------------
+#
+# `fast` = renderer.cl compiled with -cl-fast-relaxed-math -cl-mad-enable (core.clj:128).  The product's default contract
+# is the `default` build of the same source bit for bit (tests/test_gpu_device_contract.py); what is asserted here is how
+# far that build is from `fast`, per configuration.  A pixel leaves the 1e-4 band as soon as ONE hit/miss, material or
+# light decision of ONE of its passes flips under fast-math's re-association: the share grows with the passes
+# blended into a pixel and with the bounces per sample (:metal = 3), it is not a rounding that grows.
+#
+# FLOOR[key] = asserted lower bound on the fraction of pixels within 1e-4; measured values and the residual per
+# configuration: profiles/r06_pin_gfx950.txt.  Checked against the live code object where oracle/_ref travelled (every
+# pixel), else against the committed recording (tests/golden/gfx950_fast/: every pixel of the fixtures and of config 1,
+# every 997th pixel of configs 2-5) -- a clean clone reports the fraction on the sample instead of skipping.
+FLOOR = {"c1": 0.999, "c2": 0.999, "c3": 0.999, "c4": 0.999, "c5": 0.999}
+FLOOR_SCENES = 0.995  # fixture scenes: 768-3072 pixels each, one pixel = 0.03-0.13 %
 
-    16 blended passes make a pixel differ as soon as ONE hit/miss decision of one pass flips under a re-rounding:
-    the contraction-off build `strict` sits at ~60 % against `fast`.  The `default` build (contraction inside
-    expressions, 2.5-ulp divide) does not: it agrees with `fast` within 1e-4 on ~100 % of the pixels
-    (profiles/r03_pin_gfx950.txt), and the product's default contract IS that build bit for bit.  Asserted:
-      * default contract == `default` build, every float;  strict contract == `strict` build, every float;
-      * default contract within 1e-4 of `fast` on >= 99.9 % of ALL pixels, and at least as close to `fast` as the
-        CLOSEST other build of the reference is."""
+
+def _default_contract_frame(native, vox, vres, opts, mc, n):
+    with native.Context(0, contract="gfx950-default") as ctx:  # (named: this module's fixture switches unnamed contexts to "cpu")
+        ctx.set_volume(vox, vres)
+        px, _ = ctx.render_frame(opts, mc, n, want_argb=False)
+    return px
+
+
+def _report(key, r, stride, src):
+    import gfx950_pin as gp
+
+    frac = float((r <= 1e-4).mean())
+    print(f"{key}: default contract vs `fast` ({src}; {'every pixel' if stride == 1 else f'every {gp.SAMPLE_STRIDE}th pixel'}, "
+          f"{r.size} compared): {100 * frac:.4f} % within 1e-4, {100 * float((r == 0).mean()):.2f} % bit-equal, max rel {r.max():.2e}, "
+          f"{int((r > 1e-4).sum())} beyond")
+    return frac
+
+
+@pytest.mark.parametrize("config", ["c1", "c2", "c3", "c4", "c5"])
+def test_every_config_full_size_against_the_references_own_build(config, native, fast_ref, pin_default, oracle_mod):
+    """ALL FIVE BASELINE configurations at FULL size, the product in its DEFAULT contract against `fast`.  Also, where
+    the live builds are present: default contract == `default` build (every float), and at least as close to `fast` as
+    the closest other build of the reference is."""
     import bench
+    import gfx950_pin as gp
 
-    wl = bench.WORKLOADS["c2"]
+    wl = bench.WORKLOADS[config]
     vox, vres, opts, mc = bench.build_inputs(wl)
     n = wl["w"] * wl["h"]
-    px = {b: refs.gfx950_render_frame(vox, opts, mc, n, build=b, tonemap=False)[0] for b in refs.GFX950_BUILDS}
-    got = {}
-    for contract in ("gfx950-default", "gfx950-strict"):  # (named: this module's fixture switches unnamed contexts to "cpu")
-        with native.Context(0, contract=contract) as ctx:
-            ctx.set_volume(vox, vres)
-            got[contract], _ = ctx.render_frame(opts, mc, n, want_argb=False)
-    assert np.array_equal(got["gfx950-default"].view(np.uint32), px["default"].view(np.uint32))
-    assert np.array_equal(got["gfx950-strict"].view(np.uint32), px["strict"].view(np.uint32))
-    among_fast = max((rel(px["fast"], px[b]) <= 1e-4).mean() for b in ("default", "strict"))
-    r = rel(got["gfx950-default"], px["fast"])
-    frac = float((r <= 1e-4).mean())
-    frac_strict = float((rel(got["gfx950-strict"], px["fast"]) <= 1e-4).mean())
-    print(f"c2 full size: default contract vs `fast` {100 * frac:.4f} % of {n} pixels within 1e-4, {100 * float((r == 0).mean()):.2f} % "
-          f"bit-equal, max rel {r.max():.2e} (closest other reference build: {100 * among_fast:.4f} %); strict contract vs `fast` "
-          f"{100 * frac_strict:.3f} %")
-    assert frac >= 0.999
-    assert frac >= among_fast - 1e-9
-    assert len(np.unique(got["gfx950-default"].reshape(-1, 4)[::97, :3])) > 1000  # a real, chaotic frame
+    got = _default_contract_frame(native, vox, vres, opts, mc, n)
+    want, stride = fast_ref.pixels(config, vox, opts, mc, n)
+    r = gp.rel_err(got.reshape(-1, 4)[::stride], want)
+    frac = _report(config, r, stride, fast_ref.source())
+    assert frac >= FLOOR[config], (config, frac)
+    pin_default.assert_frame(config, vox, opts, mc, n, got, None)  # ... and it IS the `default` build, bit for bit
+    if fast_ref.live and config in ("c1", "c2"):  # (the strict build of the big frames: seconds of GPU time each, shown in the profile)
+        strict = oracle_mod.gfx950_render_frame(vox, opts, mc, n, build="strict", tonemap=False)[0]
+        frac_strict = float((gp.rel_err(strict, want) <= 1e-4).mean())
+        print(f"{config}: the contraction-off build `strict` vs `fast`: {100 * frac_strict:.3f} %")
+        assert frac >= frac_strict - 1e-9
+    assert len(np.unique(got.reshape(-1, 4)[::97, :3])) > 500  # a real frame
+
+
+@pytest.mark.parametrize("name", list(scenes.SCENES))
+def test_every_fixture_against_the_references_own_build(name, native, fast_ref):
+    import gfx950_pin as gp
+
+    sc = scenes.build(name)
+    got = _default_contract_frame(native, sc["vox"], sc["vres"], sc["opts"], sc["mc"], sc["n"])
+    want, stride = fast_ref.pixels(name, sc["vox"], sc["opts"], sc["mc"], sc["n"])
+    assert stride == 1
+    frac = _report(name, gp.rel_err(got, want), 1, fast_ref.source())
+    assert frac >= FLOOR_SCENES, (name, frac)
