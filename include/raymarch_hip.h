@@ -325,6 +325,13 @@ int rm_debug_get_accel(rm_ctx* ctx, int iso, uint8_t* dist_out, uint32_t* surf_o
  * the largest cube of empty in-grid cells with that cell as its corner, extending in
  * the walking direction (0 = hit cell, capped at 255). */
 int rm_debug_get_octants(rm_ctx* ctx, int iso, uint8_t* oct_out);
+/* The part of the image height (fractions, 0 = top row; *lo = *hi = 0: none) whose tile rows the frame kernel
+ * dispatches FIRST: the rows in which the clip box [voxelBoundsMin, voxelBoundsMax] of the 544-byte record `opts`
+ * covers at least half as much of the image's width as in the row where it covers most -- the box's edges through the
+ * inverse of cameraRayLookat (renderer.cl:456-465).  A scheduling heuristic (longest jobs first; then the rows below
+ * the band, the rows above it -- sky -- as the tail of a blocking frame; RAYMARCH_ROW_ORDER=desc|asc switch it off):
+ * pixels never depend on it.  Host-side, no device needed. */
+int rm_debug_volume_band(const void* opts, double* lo, double* hi);
 
 /* ---- host-side parameter layer (no device needed) ------------------------
  * The reference builds its inputs in Clojure; a non-Python host gets the same

@@ -68,7 +68,7 @@ EXPORTS = [
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_frame_device_argb", "rm_resolve_device_argb", "rm_last_frame_breakdown",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_selftest_prims", "rm_selftest_filter",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_debug_volume_band", "rm_selftest_prims", "rm_selftest_filter",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
@@ -76,6 +76,14 @@ EXPORTS = [
 
 # rm_set_contract names (include/raymarch_hip.h): whose arithmetic the kernels reproduce
 CONTRACTS = {"cpu": 0, "gfx950": 1, "gfx950-strict": 1, "gfx950-default": 2}
+
+
+def volume_band(opts_record):
+    """-> (lo, hi): the part of the image height whose tile rows a frame of this 544-byte record dispatches first
+    (rm_debug_volume_band; (0, 0) = none).  Host-side."""
+    lo, hi = ctypes.c_double(), ctypes.c_double()
+    check(lib().rm_debug_volume_band(bytes(opts_record[:OPTS_BYTES]), ctypes.byref(lo), ctypes.byref(hi)))
+    return float(lo.value), float(hi.value)
 
 
 class RmError(RuntimeError):
@@ -232,6 +240,7 @@ def lib():
     L.rm_selftest_filter.argtypes = [_vp, _vp, _vp, _i, _vp]
     L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
     L.rm_debug_get_octants.argtypes = [_vp, _i, _vp]
+    L.rm_debug_volume_band.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
 

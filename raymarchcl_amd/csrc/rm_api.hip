@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -95,6 +96,8 @@ struct rm_ctx {
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
   bool rows_desc = true;     // RAYMARCH_ROW_ORDER=asc: tile rows top to bottom (rounds 2-4); default bottom to top
+  bool rows_band = true;     // ... with the rows that can see the clip box first (round 6); RAYMARCH_ROW_ORDER=desc: plain bottom to top
+  double band_fixed_lo = 0.0, band_fixed_hi = 0.0;  // RAYMARCH_ROW_BAND=lo,hi (fractions of the image height): that band instead
   int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most.  Default 4 =
                              // 4 pixels x 16 passes, measured best for full groups (64 passes as 4 x 16 / 2 x 32 / 1 x 64:
                              // 136.0 / 137.3 / 140.3 ms) ...
@@ -304,6 +307,89 @@ int render_pass_host(rm_ctx* c, const float* mc, const void* opts544, float* pix
   return RM_OK;
 }
 
+// The band of tile rows that holds most of a frame's work: the rows in which the clip box of the volume covers at least
+// half as much of the image's width as in the row where it covers most (fractions of the image height, 0 = top row;
+// *lo = *hi = 0: no band).  Coverage per tile row = extent of the box's projection along that row: the twelve edges of
+// [voxelBoundsMin, voxelBoundsMax] in the view space of record `o`'s camera -- the inverse of the reference's
+// cameraRayLookat (renderer.cl:456-465: direction = right * x + up * y + forward with x, y linear in the pixel position)
+// --, clipped against a near plane, projected, and cut by the row's line (the projection of a convex box is the hull of its
+// projected edges).  A HEURISTIC for scheduling only -- the frame kernel dispatches these rows first, the rows below them
+// next, the rows above them (sky in the reference's scenes) last --: a poor band costs time, never pixels.
+static void volume_band(const RmOpts& o, double* lo, double* hi) {
+  *lo = *hi = 0.0;
+  const double e[3] = {o.eyePos[0], o.eyePos[1], o.eyePos[2]};
+  double f[3] = {o.targetPos[0] - e[0], o.targetPos[1] - e[1], o.targetPos[2] - e[2]};
+  const double fl = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+  const int resy = o.resolution[1];
+  if (!(fl > 1e-9) || !(o.fov > 1e-6f) || !(o.invAspect > 1e-6f) || resy < 16 || resy > (1 << 16)) return;
+  for (double& v : f) v /= fl;
+  double r[3] = {f[1] * o.up[2] - f[2] * o.up[1], f[2] * o.up[0] - f[0] * o.up[2], f[0] * o.up[1] - f[1] * o.up[0]};
+  const double rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (!(rl > 1e-9)) return;
+  for (double& v : r) v /= rl;
+  const double u[3] = {r[1] * f[2] - r[2] * f[1], r[2] * f[0] - r[0] * f[2], r[0] * f[1] - r[1] * f[0]};
+  double cv[8][3];  // view-space corners: (right, up, forward) components
+  for (int k = 0; k < 8; k++) {
+    const double p[3] = {(k & 1 ? o.voxelBoundsMax[0] : o.voxelBoundsMin[0]) - e[0],
+                         (k & 2 ? o.voxelBoundsMax[1] : o.voxelBoundsMin[1]) - e[1],
+                         (k & 4 ? o.voxelBoundsMax[2] : o.voxelBoundsMin[2]) - e[2]};
+    cv[k][0] = p[0] * r[0] + p[1] * r[1] + p[2] * r[2];
+    cv[k][1] = p[0] * u[0] + p[1] * u[1] + p[2] * u[2];
+    cv[k][2] = p[0] * f[0] + p[1] * f[1] + p[2] * f[2];
+  }
+  // the edges in front of the near plane, projected: (x, y) of the view vector at both ends
+  const double cmin = 0.02;
+  double seg[12][4];
+  int nseg = 0;
+  for (int k = 0; k < 8; k++)
+    for (int ax = 0; ax < 3; ax++) {
+      if (k & (1 << ax)) continue;
+      const double* A = cv[k];
+      const double* B = cv[k | (1 << ax)];
+      double t0 = 0.0, t1 = 1.0;
+      const double ga = A[2] - cmin, gb = B[2] - cmin;
+      if (ga < 0.0 && gb < 0.0) continue;
+      if (ga < 0.0) t0 = ga / (ga - gb);
+      else if (gb < 0.0) t1 = ga / (ga - gb);
+      for (int q = 0; q < 2; q++) {
+        const double t = q ? t1 : t0;
+        const double c = std::max(A[2] + t * (B[2] - A[2]), cmin);
+        seg[nseg][2 * q] = (A[0] + t * (B[0] - A[0])) / c;
+        seg[nseg][2 * q + 1] = (A[1] + t * (B[1] - A[1])) / c;
+      }
+      nseg++;
+    }
+  if (!nseg) return;
+  const int rows = (resy + 7) / 8;
+  const double hx = 0.5 * (double)o.fov;  // |x| of the view vector at the image's sides
+  std::vector<double> cov((size_t)rows, 0.0);
+  double best = 0.0;
+  for (int j = 0; j < rows; j++) {
+    const double py = std::min((double)j * 8.0 + 4.0, (double)resy - 0.5);
+    const double Y = -(double)o.invAspect * (py / (double)resy * (double)o.fov - 0.5 * (double)o.fov);  // renderer.cl:461-463
+    double x0 = 1e30, x1 = -1e30;
+    for (int q = 0; q < nseg; q++) {
+      const double ya = seg[q][1] - Y, yb = seg[q][3] - Y;
+      if (ya * yb > 0.0 || ya == yb) continue;
+      const double x = seg[q][0] + ya / (ya - yb) * (seg[q][2] - seg[q][0]);
+      x0 = std::min(x0, x);
+      x1 = std::max(x1, x);
+    }
+    if (x1 >= x0) cov[(size_t)j] = std::max(0.0, std::min(x1, hx) - std::max(x0, -hx)) / (2.0 * hx);
+    best = std::max(best, cov[(size_t)j]);
+  }
+  if (!(best > 0.0)) return;  // the box is nowhere in the image: no row walks the tables, any order will do
+  int r0 = -1, r1 = -1;
+  for (int j = 0; j < rows; j++)
+    if (cov[(size_t)j] >= 0.5 * best) {
+      if (r0 < 0) r0 = j;
+      r1 = j + 1;
+    }
+  if (r0 <= 0 && r1 >= rows) return;  // every row is about as heavy: plain bottom to top
+  *lo = (double)r0 / (double)rows;
+  *hi = (double)r1 / (double)rows;
+}
+
 // What a frame writes: tile-major accumulators of a partition (the multi-GPU exchange unit),
 // or -- unpartitioned -- the row-major float4 image and, with the last pass, the ARGB image.
 struct FrameOut {
@@ -376,6 +462,8 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.pp_log2 = pp_log2;
     f.xcd_rows = c->xcd_rows;
     f.rows_desc = c->rows_desc;
+    if (c->band_fixed_hi > c->band_fixed_lo) { f.band_lo = c->band_fixed_lo; f.band_hi = c->band_fixed_hi; }
+    else if (c->rows_band && !sdf_frame) volume_band(host_recs[0], &f.band_lo, &f.band_hi);
     f.accumulate = i0 > 0;
     f.row_major = out.row_major;
     f.arith = contract_arith(c, sdf_frame);
@@ -475,6 +563,8 @@ static int create_one(int device_id, rm_ctx** out) {
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* ro = getenv("RAYMARCH_ROW_ORDER");
   if (ro) c->rows_desc = !(ro[0] == 'a');
+  if (ro) c->rows_band = ro[0] == 'b';  // "band" (default) / "desc" / "asc"
+  if (const char* rb = getenv("RAYMARCH_ROW_BAND")) (void)sscanf(rb, "%lf,%lf", &c->band_fixed_lo, &c->band_fixed_hi);
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) { c->pass_pack = atoi(pk); c->pass_pack_auto = false; }
   const char* bk = getenv("RAYMARCH_BRICKS");
@@ -1281,6 +1371,14 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
     HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
   if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RM_OK;
+}
+
+int rm_debug_volume_band(const void* opts, double* lo, double* hi) {
+  if (!opts || !lo || !hi) return fail(RM_EINVAL, "null argument");
+  RmOpts o;
+  memcpy(&o, opts, sizeof(o));
+  volume_band(o, lo, hi);
   return RM_OK;
 }
 

@@ -45,6 +45,9 @@ struct FrameLaunch {
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
   bool rows_desc = true;           // with xcd_rows: tile rows dispatched bottom to top (the top rows -- sky -- make the shortest tail)
+  // with rows_desc: the part of the image height (fractions, 0 = top) whose rows are dispatched FIRST -- the rows that can see
+  // the clip box (rm_api.hip volume_band); band_hi <= band_lo: none
+  double band_lo = 0.0, band_hi = 0.0;
   // arithmetic contract (rm_math.hpp ArithOf): 0 = OpenCL CPU device, 1 = the same with the GPU lowering of
   // the seed casts (rm_set_seed_cast), 2 / 3 = ROCm's OpenCL library on this GPU as the strict / default
   // build of the reference uses it (rm_set_contract).  Every launcher below takes the same number.

@@ -130,6 +130,9 @@ struct FrameArgs {
   unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int rows_desc;                       // XCD-aware order: tile rows dispatched bottom to top
+  int band_r0, band_r1;                // ... and, when band_r1 > band_r0, the tile rows [band_r0, band_r1) FIRST: the rows whose
+                                       // primary rays can meet the clip box (rm_api.hip volume_band), then the rows below them,
+                                       // the rows above them -- sky in the reference's scenes -- last
   int row_major;                       // acc is indexed by work-item id instead of slot*64 + pixel
 };
 
@@ -173,7 +176,16 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     // config 5 -3.5 %, config 3 +1.1 %, config 4 +0.2 % (RAYMARCH_ROW_ORDER=asc restores the old order).
     const long long rows = (long long)gridDim.x / a.bpr;  // (padded to a multiple of 8: surplus blocks exit at once)
     const long long row = (m / a.bpr) * 8 + k;
-    lb = (a.rows_desc ? rows - 1 - row : row) * a.bpr + (m % a.bpr);
+    // ... THE ROWS THAT SEE THE VOLUME FIRST (round 6): the costly wavefronts are the ones whose rays walk the tables; they
+    // go out first (bottom to top), then the ground rows below them, the rows above them last -- the longest jobs first and
+    // the shortest as the tail.  The band comes from the clip box's projection through the camera of record 0 (host).
+    long long at_row = a.rows_desc ? rows - 1 - row : row;
+    const long long nb = (long long)a.band_r1 - a.band_r0;
+    if (nb > 0) {
+      const long long below = rows - a.band_r1;  // (incl. the padding rows, whose blocks exit at once)
+      at_row = row < nb ? a.band_r1 - 1 - row : (row < nb + below ? rows - 1 - (row - nb) : a.band_r0 - 1 - (row - nb - below));
+    }
+    lb = at_row * a.bpr + (m % a.bpr);
   }
   // wavefronts of a tile are consecutive: tile slot = w / pp, sub-block = w % pp
   const long long slot = lb >> pp_log2;
@@ -494,6 +506,15 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.tiles_per_part = tpp; a.pp_log2 = pp_log2; a.passes = f.passes; a.bpr = bpr;
   a.accumulate = f.accumulate ? 1 : 0;
   a.rows_desc = f.rows_desc ? 1 : 0;
+  a.band_r0 = a.band_r1 = 0;
+  if (bpr > 0 && f.rows_desc && f.band_hi > f.band_lo) {  // image-height fractions -> rows of this launch's grid
+    const long long my_blocks = (long long)tpp << pp_log2;
+    const long long rows_real = (my_blocks + bpr - 1) / bpr;
+    long long r0 = (long long)(f.band_lo * (double)rows_real), r1 = (long long)(f.band_hi * (double)rows_real) + 1;
+    r0 = r0 < 0 ? 0 : r0;
+    r1 = r1 > rows_real ? rows_real : r1;
+    if (r1 > r0) { a.band_r0 = (int)r0; a.band_r1 = (int)r1; }
+  }
   a.row_major = f.row_major ? 1 : 0;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   if (f.passes > (1 << pp_log2)) return hipErrorInvalidValue;  // (the caller splits a run into such launches)

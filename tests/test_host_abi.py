@@ -82,3 +82,60 @@ def test_eyepos_scatter_gyroid_vox(native, tmp_path):
     assert L.rm_vox_load(q.encode(), w.ctypes.data, w.size) == 0 and np.array_equal(w, v)
     assert L.rm_vox_load(q.encode(), w.ctypes.data, 10) != 0 and b"too small" in L.rm_last_error()
     assert L.rm_vox_info(b"/nonexistent.vox", ctypes.byref(rx), ctypes.byref(ry), ctypes.byref(rz)) != 0
+
+
+def test_volume_band_is_the_rows_where_the_clip_box_covers_most(native):
+    """rm_debug_volume_band (the tile rows the frame kernel dispatches first) against a brute-force slab test of every
+    pixel's central ray (renderer.cl:456-465 camera, :153-161 slab test): the band is the run of tile rows in which the box
+    covers at least half as much of the width as in the best row; no band when that is every row (BASELINE's camera: the
+    box fills the view) or when the box is not in the image."""
+    import numpy as np
+
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import structs
+
+    def coverage(o, w, h):
+        eye, tgt, up = np.array(o["eyePos"], float), np.array(o["targetPos"], float), np.array(o["up"], float)
+        f = tgt - eye
+        f /= np.linalg.norm(f)
+        r = np.cross(f, up)
+        r /= np.linalg.norm(r)
+        u = np.cross(r, f)
+        px, py = np.meshgrid(np.arange(w) + 0.5, np.arange(h) + 0.5)
+        vx = px / w * o["fov"] - o["fov"] * 0.5
+        vy = -(py / h * o["fov"] - o["fov"] * 0.5) * o["invAspect"]
+        d = r[None, None] * vx[..., None] + u[None, None] * vy[..., None] + f[None, None]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lo = (np.array(o["voxelBoundsMin"]) - eye) / d
+            hi = (np.array(o["voxelBoundsMax"]) - eye) / d
+        near = np.maximum(np.minimum(lo, hi).max(axis=-1), 0.0)
+        far = np.maximum(lo, hi).min(axis=-1)
+        return (far > near)[4::8].mean(axis=1)  # the centre line of every tile row
+
+    cases = [dict(eyepos=rm.compute_eyepos(-45, 2.25, 0.35), targetpos=[0, -0.4, 0], dof=0.025),   # BASELINE configs: no band
+             dict(eyepos=rm.compute_eyepos(20, 5.0, 1.5), targetpos=[0, -0.15, 0]),               # a distant camera
+             dict(eyepos=rm.compute_eyepos(135, 6.0, 3.5), targetpos=[0, 0, 0], fov=60),
+             dict(eyepos=rm.compute_eyepos(-45, 4.0, 0.35), targetpos=[0, 1.5, 0]),               # the box low in the image
+             dict(eyepos=rm.compute_eyepos(10, 0.6, 0.3), targetpos=[0.2, 0.1, 0.0]),             # inside the box
+             dict(eyepos=rm.compute_eyepos(0, 4.0, 0.0), targetpos=[0, 6.0, -4.0])]               # the box out of view
+    seen = set()
+    for k, kw in enumerate(cases):
+        w, h = 320, 184
+        o = rm.render_options(width=w, height=h, vres=[64] * 3, iter=1, mat="orange-stripes", **kw)
+        lo, hi = native.volume_band(structs.encode_bytes(o))
+        cov = coverage(o, w, h)
+        rows = len(cov)
+        assert 0.0 <= lo <= hi <= 1.0
+        want = np.nonzero(cov >= 0.5 * cov.max())[0] if cov.max() > 0 else np.array([], int)
+        if hi > lo:
+            seen.add("band")
+            r0, r1 = lo * rows, hi * rows
+            assert abs(r0 - want.min()) <= 1.01 and abs(r1 - (want.max() + 1)) <= 1.01, (k, r0, r1, want.min(), want.max())
+            assert r1 - r0 < rows
+        else:
+            seen.add("none")
+            assert want.size == 0 or (want.min() <= 1 and want.max() >= rows - 2), (k, want)
+    assert seen == {"band", "none"}
+    for cfg_w, cfg_h in ((1280, 720), (1920, 1080), (3840, 2160)):  # BASELINE's camera: the box fills the view, plain order
+        o = rm.render_options(width=cfg_w, height=cfg_h, vres=[256] * 3, iter=16, mat="orange-stripes", **cases[0])
+        assert native.volume_band(structs.encode_bytes(o)) == (0.0, 0.0)
