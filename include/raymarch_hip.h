@@ -210,10 +210,12 @@ int rm_tonemap_image(rm_ctx* ctx, const float* pixels, const void* opts544, uint
  * rm_pin_host_buffer move by DMA at PCIe speed; others go through the runtime's
  * pageable staging path.  At BASELINE config 2 a caller that reads back only the ARGB image,
  * as the reference's pipeline does (core.clj:91-97), pays the kernel + ~0.2 ms either way.)
- * PERFORMANCE CLIFF: records with aoIter > 7 (more than RM_WAVE_AO_PROBES = 8 AO probes per hit; the
- * reference's default is aoIter = 5) do not fit the exchange area through which a wavefront shares its
- * secondary rays: such passes go out one launch per pass through the single-pass kernels (each lane traces its own
- * probes and shadow rays), about 2-3x the time per pass.  Results are bit-identical either way. */
+ * aoIter > 7 (more than RM_WAVE_AO_PROBES = 8 AO probes per hit, the result slots of the exchange area through which a
+ * wavefront shares its secondary rays; the reference's default is aoIter = 5): on cubic 256^3, 512^3 and 1024^3
+ * volumes -- BASELINE's -- the frame kernel takes the probes in chunks of 8, the time follows the probe count
+ * (config 2: 9 / 12 / 16 probes = 1.16 / 1.34 / 1.63 x the time of 6; round 5: 2-3 x per pass).  On every other grid
+ * such passes still go out one launch per pass through the single-pass kernels (each lane traces its own probes and
+ * shadow rays), about 2-3 x the time per pass.  Results are bit-identical either way. */
 int rm_render_frame(rm_ctx* ctx, const void* opts_array, const float* mc_array, int iter, int n,
                     float* pixels_out, uint32_t* argb_out);
 

@@ -428,12 +428,18 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     const size_t acc_bytes = out.row_major ? (size_t)n * 16
                                            : (size_t)rmk::tiles_per_part(rmk::tiles_total(resx, n), out.tile_stride) * 64 * 16;
     // A record that asks for more AO probes than a wavefront's exchange area holds results for (8: the
-    // reference's default is aoIter = 5 -> 6 probes) goes through the single-pass kernel, one launch per pass
-    // (each lane traces its own secondary rays there); the frame kernel carries no second AO path for it.
+    // reference's default is aoIter = 5 -> 6 probes): the frame kernels of the table layouts with the grid edge
+    // compiled in (256^3, 512^3, 1024^3 volumes: BASELINE's) take the probes in chunks of 8 (rm_shade.hpp
+    // occlusion_wave); on the generic layouts such a record goes through the single-pass kernel, one launch per pass
+    // (each lane traces its own secondary rays there) -- their frame kernels carry no second AO path for it.
+    bool single_pass = false;
+    rmk::Accel accel;
     if (!sdf_frame && host_recs[i0].aoIter + 1 > RM_WAVE_AO_PROBES) {
-      rmk::Accel accel;
       int rc = ensure_accel(c, host_recs[i0].isoVal, &accel);
       if (rc) return rc;
+      single_pass = !rmk::frame_takes_any_ao(accel);
+    }
+    if (single_pass) {
       if (i0 == 0) HIP_TRY(hipMemsetAsync(out.acc, 0, acc_bytes, c->stream));
       HIP_TRY(rmk::launch_render_pass(c->stream, c->vol->d_vox, accel, d_mc + (size_t)i0 * RM_TABLE_FLOATS, d_opts + i0,
                                       resx, out.acc, n, 0, n, out.tile_first, out.tile_stride, !out.row_major, nullptr,

@@ -54,6 +54,8 @@ struct FrameLaunch {
   int arith = 0;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
+// true: the frame kernel of this volume's table layout takes records with any number of AO probes (chunked exchange)
+bool frame_takes_any_ao(const Accel& accel);
 
 int choose_pass_pack(int passes, int max_log2, int waste_pct = 60);
 // tiles a partition of `parts` owns at most: ceil(tiles_total / parts)

@@ -413,6 +413,11 @@ int layout_of(const rmk::Accel& accel, bool frame) {
   return accel.log2res ? 2 : 0;
 }
 
+// Does the frame kernel of this volume's table layout take records with ANY number of AO probes (rm_shade.hpp
+// kChunkedAO: layouts 3, 4, 5)?  Otherwise frames whose records ask for more than RM_WAVE_AO_PROBES go pass by pass
+// through the single-pass kernels (rm_api.hip frame_on_device).
+bool frame_takes_any_ao(const rmk::Accel& accel) { return rmk::fixed_log2(layout_of(accel, true)) != 0; }
+
 hipError_t launch_render_pass(hipStream_t st, const uint8_t* vox, Accel accel, const float* mc,
                               const RmOpts* d_opts, int resx, float* pixels, int n, int id0,
                               int id1, int tile_first, int tile_stride, bool tile_major,

@@ -949,12 +949,20 @@ struct Tracer {
   }
 
   // occlusion() for all lanes of the wavefront at once; `active` lanes own a hit
+  //
+  // The exchange area has kWaveLdsRes result slots per owner.  kChunkedAO (the table layouts with the grid edge compiled
+  // in: 3, 4, 5 -- the ones BASELINE's configurations use): a record that asks for more probes gets them in CHUNKS of that
+  // many -- the owners fold a chunk's results into their product (renderer.cl:338-344, in probe order, with the reference's
+  // early exit) before the next chunk overwrites them --, so any aoIter goes through the frame kernel.  The generic layouts
+  // (0, 1, 2) keep one chunk: three more launch-uniform values tip their instantiations over the scalar register file
+  // (2-4 spilled SGPRs, refused by the build's lint, round 5), and the host sends their frames with more than
+  // kWaveLdsRes probes through the single-pass kernels (rm_api.hip frame_on_device, rmk::frame_takes_any_ao).
+  static constexpr bool kChunkedAO = fixed_log2(LAYOUT) != 0;
   RM_DEV float occlusion_wave(bool active, const Sample& s, v3 pos, v3 normal) {
     const RmOpts& o = *sc.o;
-    // (aoIter + 1 <= kWaveLdsRes: the host sends frames whose records ask for more probes through the single-pass kernels.
-    //  The clamp keeps a record rewritten in place behind the host's validation from writing past the exchange area:
-    //  such a frame gets too few probes, never corrupted LDS.)
-    const int np = min(o.aoIter + 1, kWaveLdsRes);
+    // (one chunk: the clamp keeps a record rewritten in place behind the host's validation from writing past the exchange
+    //  area: such a frame gets too few probes, never corrupted LDS)
+    const int np_all = kChunkedAO ? o.aoIter + 1 : min(o.aoIter + 1, kWaveLdsRes);
     const Deal dl = deal(active);
     if (dl.owners == 0) return 1.0f;
     const uint32_t seed0 =
@@ -969,44 +977,48 @@ struct Tracer {
       lds_map(dl.my_rank) = dl.lane;
     }
     wave_sync();
-    const int tasks = np * dl.owners;
-    for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
-      const int t = base + dl.my_slot;
-      if (t < tasks) {
-        int probe, rank;
-        divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
-        const int owner = lds_map(rank);
-        const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
-        const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
-        const uint32_t seed = __float_as_uint(lds_in(6, owner)) + 37u * (uint32_t)(probe + 1);
-        const float4* tab = reinterpret_cast<const float4*>(
-            (unsigned long long)__float_as_uint(lds_in(7, owner)) |
-            ((unsigned long long)__float_as_uint(lds_in(8, owner)) << 32));
-        float d = 0.0f, dj = 0.0f;  // d of probe i = i+1 sequential adds (renderer.cl:339)
-        for (int j = 0; j < np; j++) {
-          dj += o.aoStepDist;
-          if (j == probe) d = dj;
+    float ao = 1.0f, dsum = 0.0f;  // the owner's running product and probe distance (renderer.cl:336-339)
+    for (int p0 = 0; p0 < np_all; p0 += kWaveLdsRes) {  // uniform; ONE trip unless kChunkedAO and aoIter > 7
+      const int np = kChunkedAO ? min(np_all - p0, kWaveLdsRes) : np_all;
+      const int tasks = np * dl.owners;
+      for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
+        const int t = base + dl.my_slot;
+        if (t < tasks) {
+          int probe, rank;
+          divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
+          const int owner = lds_map(rank);
+          const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
+          const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
+          const int gp = kChunkedAO ? p0 + probe : probe;  // the probe's number in the record's loop
+          const uint32_t seed = __float_as_uint(lds_in(6, owner)) + 37u * (uint32_t)(gp + 1);
+          const float4* tab = reinterpret_cast<const float4*>(
+              (unsigned long long)__float_as_uint(lds_in(7, owner)) |
+              ((unsigned long long)__float_as_uint(lds_in(8, owner)) << 32));
+          float d = 0.0f, dj = 0.0f;  // d of probe i = i+1 sequential adds (renderer.cl:339)
+          for (int j = 0; j < np_all; j++) {
+            dj += o.aoStepDist;
+            if (j == gp) d = dj;
+          }
+          const float4 r = tab[seed & (RM_TABLE_ENTRIES - 1)];
+          const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, onrm));
+          float sd, scode;
+          v3 nn;
+          const v3 rpos = mads(n, d, opos);
+          const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
+          scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
+          lds_res(probe, owner) = sd;
         }
-        const float4 r = tab[seed & (RM_TABLE_ENTRIES - 1)];
-        const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, onrm));
-        float sd, scode;
-        v3 nn;
-        const v3 rpos = mads(n, d, opos);
-        const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
-        scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
-        lds_res(probe, owner) = sd;
       }
-    }
-    wave_sync();
-    float ao = 1.0f;
-    if (active) {
-      float d = 0.0f;
-      for (int i = 0; i < np && (double)ao > 0.01; i++) {  // renderer.cl:338-344
-        d += o.aoStepDist;
-        ao *= 1.0f - M::fmax(M::div((d - lds_res(i, dl.lane)) * o.aoAmp, d), 0.0f);
+      wave_sync();
+      if (active) {
+        for (int i = 0; i < np && (double)ao > 0.01; i++) {  // renderer.cl:338-344 (a product that has stopped stays stopped)
+          dsum += o.aoStepDist;
+          ao *= 1.0f - M::fmax(M::div((dsum - lds_res(i, dl.lane)) * o.aoAmp, dsum), 0.0f);
+        }
       }
+      wave_sync();  // the results are consumed: the next chunk / the next shared phase may overwrite them
+      if (!kChunkedAO) break;
     }
-    wave_sync();  // the posted values are dead: the next shared phase may overwrite them
     return ao;
   }
 

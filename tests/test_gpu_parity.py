@@ -412,3 +412,51 @@ def test_records_with_more_ao_probes_than_a_wavefront_exchanges(native, oracle_m
         assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb)
         _none, argb2 = ctx.render_frame(opts, mc, n, want_pixels=False)
         assert np.array_equal(argb2, want_argb)
+
+
+@pytest.mark.parametrize("ao_iter", [7, 8, 11, 16])
+def test_any_number_of_ao_probes_through_the_frame_kernel_on_baselines_grids(native, oracle_mod, ao_iter):
+    """On the table layouts with the grid edge compiled in (256^3 here: layout 5; BASELINE's 512^3 and 1024^3 likewise) the
+    frame kernel takes the AO probes of a record in chunks of 8 (rm_shade.hpp occlusion_wave, kChunkedAO): ONE launch per
+    16 passes whatever aoIter (no single-pass route, round 5's cliff), bit-identical to the oracle -- also with an AO
+    product that stops early (renderer.cl:338: `ao > 0.01`) inside the first chunk, as partitions inside the library, and
+    in the device contracts against the reference kernel itself where it travelled."""
+    import raymarchcl_amd as rm
+    from raymarchcl_amd import generators as gen, structs
+
+    it, w, h = 4, 64, 40
+    vox = scenes.volume("gyroid", 256)
+
+    def records(**over):
+        recs = []
+        for i in range(it):
+            o = rm.render_options(width=w, height=h, vres=[256] * 3, t=i * 0.333, iter=it,
+                                  eyepos=rm.compute_eyepos(-45, 2.25, 0.35), targetpos=[0, -0.4, 0], mat="orange-stripes", dof=0.025)
+            o["aoIter"] = ao_iter
+            o["aoStepDist"] = 0.02
+            o.update(over)
+            recs.append(structs.encode_bytes(o))
+        return b"".join(recs)
+
+    mc = np.stack([gen.generate_scatter_offsets(0x4000, seed=90 + i) for i in range(it)])
+    n = w * h
+    for over in ({}, dict(aoAmp=3.0)):  # (aoAmp 3: most products fall below 0.01 within the first probes)
+        opts = records(**over)
+        want, want_argb = oracle_mod.render_frame(vox, opts, mc, n)
+        with native.Context(0, contract="cpu") as ctx:
+            ctx.set_volume(vox, (256,) * 3)
+            px, argb = ctx.render_frame(opts, mc, n)
+            ms, launches = ctx.last_frame_timing()
+        assert launches == 1, (ao_iter, launches)  # the frame kernel, not one single-pass launch per pass
+        assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb), (ao_iter, over)
+    with native.Context([0, 0, 0], contract="cpu") as ctx:
+        ctx.set_volume(vox, (256,) * 3)
+        px, argb = ctx.render_frame(opts, mc, n)
+        assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb)
+    if oracle_mod.have_gfx950_ref("default"):
+        for build, contract in (("default", "gfx950-default"), ("strict", "gfx950-strict")):
+            ref_px, ref_argb, _ = oracle_mod.gfx950_render_frame(vox, opts, mc, n, build=build)
+            with native.Context(0, contract=contract) as ctx:
+                ctx.set_volume(vox, (256,) * 3)
+                px, argb = ctx.render_frame(opts, mc, n)
+            assert np.array_equal(px.view(np.uint32), ref_px.view(np.uint32)) and np.array_equal(argb, ref_argb), (ao_iter, build)
