@@ -959,10 +959,75 @@ struct Tracer {
   // kWaveLdsRes probes through the single-pass kernels (rm_api.hip frame_on_device, rmk::frame_takes_any_ao).
   static constexpr bool kChunkedAO = fixed_log2(LAYOUT) != 0;
   RM_DEV float occlusion_wave(bool active, const Sample& s, v3 pos, v3 normal) {
+    if constexpr (kChunkedAO) return occlusion_wave_chunks(active, s, pos, normal);
+    else return occlusion_wave_one_chunk(active, s, pos, normal);
+  }
+  // the generic layouts' form: ONE chunk (spelled out on its own: the chunk loop below with a constant trip count still costs
+  // their instantiations 2 spilled SGPRs)
+  RM_DEV float occlusion_wave_one_chunk(bool active, const Sample& s, v3 pos, v3 normal) {
     const RmOpts& o = *sc.o;
-    // (one chunk: the clamp keeps a record rewritten in place behind the host's validation from writing past the exchange
-    //  area: such a frame gets too few probes, never corrupted LDS)
-    const int np_all = kChunkedAO ? o.aoIter + 1 : min(o.aoIter + 1, kWaveLdsRes);
+    // (aoIter + 1 <= kWaveLdsRes: the host sends frames whose records ask for more probes through the single-pass kernels.
+    //  The clamp keeps a record rewritten in place behind the host's validation from writing past the exchange area:
+    //  such a frame gets too few probes, never corrupted LDS.)
+    const int np = min(o.aoIter + 1, kWaveLdsRes);
+    const Deal dl = deal(active);
+    if (dl.owners == 0) return 1.0f;
+    const uint32_t seed0 =
+        seed_of(M::fuse(s.time, 2671.918f, M::fuse(pos.z, 2945.87f, M::fuse(pos.x, 3183.75f, pos.y * 1831.42f))));
+    if (active) {
+      lds_in(0, dl.lane) = pos.x; lds_in(1, dl.lane) = pos.y; lds_in(2, dl.lane) = pos.z;
+      lds_in(3, dl.lane) = normal.x; lds_in(4, dl.lane) = normal.y; lds_in(5, dl.lane) = normal.z;
+      lds_in(6, dl.lane) = __uint_as_float(seed0);
+      const unsigned long long tp = (unsigned long long)mc_;
+      lds_in(7, dl.lane) = __uint_as_float((uint32_t)tp);
+      lds_in(8, dl.lane) = __uint_as_float((uint32_t)(tp >> 32));
+      lds_map(dl.my_rank) = dl.lane;
+    }
+    wave_sync();
+    const int tasks = np * dl.owners;
+    for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
+      const int t = base + dl.my_slot;
+      if (t < tasks) {
+        int probe, rank;
+        divmod_small(t, dl.owners, probe, rank);  // probe-major: a round holds probes of one distance
+        const int owner = lds_map(rank);
+        const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
+        const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
+        const uint32_t seed = __float_as_uint(lds_in(6, owner)) + 37u * (uint32_t)(probe + 1);
+        const float4* tab = reinterpret_cast<const float4*>(
+            (unsigned long long)__float_as_uint(lds_in(7, owner)) |
+            ((unsigned long long)__float_as_uint(lds_in(8, owner)) << 32));
+        float d = 0.0f, dj = 0.0f;  // d of probe i = i+1 sequential adds (renderer.cl:339)
+        for (int j = 0; j < np; j++) {
+          dj += o.aoStepDist;
+          if (j == probe) d = dj;
+        }
+        const float4 r = tab[seed & (RM_TABLE_ENTRIES - 1)];
+        const v3 n = normalize(mads(V(r.x, r.y, r.z), 0.2f, onrm));
+        float sd, scode;
+        v3 nn;
+        const v3 rpos = mads(n, d, opos);
+        const int ao_limit = ao_walk_limit(d, rpos.y + o.groundY, o.maxVoxelIter / 2);
+        scene_distance(rpos, n, o.maxVoxelIter / 2, false, sd, scode, nn, false, ao_limit);
+        lds_res(probe, owner) = sd;
+      }
+    }
+    wave_sync();
+    float ao = 1.0f;
+    if (active) {
+      float d = 0.0f;
+      for (int i = 0; i < np && (double)ao > 0.01; i++) {  // renderer.cl:338-344
+        d += o.aoStepDist;
+        ao *= 1.0f - M::fmax(M::div((d - lds_res(i, dl.lane)) * o.aoAmp, d), 0.0f);
+      }
+    }
+    wave_sync();  // the posted values are dead: the next shared phase may overwrite them
+    return ao;
+  }
+
+  RM_DEV float occlusion_wave_chunks(bool active, const Sample& s, v3 pos, v3 normal) {
+    const RmOpts& o = *sc.o;
+    const int np_all = o.aoIter + 1;
     const Deal dl = deal(active);
     if (dl.owners == 0) return 1.0f;
     const uint32_t seed0 =
@@ -978,8 +1043,8 @@ struct Tracer {
     }
     wave_sync();
     float ao = 1.0f, dsum = 0.0f;  // the owner's running product and probe distance (renderer.cl:336-339)
-    for (int p0 = 0; p0 < np_all; p0 += kWaveLdsRes) {  // uniform; ONE trip unless kChunkedAO and aoIter > 7
-      const int np = kChunkedAO ? min(np_all - p0, kWaveLdsRes) : np_all;
+    for (int p0 = 0; p0 < np_all; p0 += kWaveLdsRes) {  // uniform; ONE trip unless aoIter > 7
+      const int np = min(np_all - p0, kWaveLdsRes);
       const int tasks = np * dl.owners;
       for (int base = 0; base < tasks; base += dl.helpers) {  // uniform trip count
         const int t = base + dl.my_slot;
@@ -989,7 +1054,7 @@ struct Tracer {
           const int owner = lds_map(rank);
           const v3 opos = V(lds_in(0, owner), lds_in(1, owner), lds_in(2, owner));
           const v3 onrm = V(lds_in(3, owner), lds_in(4, owner), lds_in(5, owner));
-          const int gp = kChunkedAO ? p0 + probe : probe;  // the probe's number in the record's loop
+          const int gp = p0 + probe;  // the probe's number in the record's loop
           const uint32_t seed = __float_as_uint(lds_in(6, owner)) + 37u * (uint32_t)(gp + 1);
           const float4* tab = reinterpret_cast<const float4*>(
               (unsigned long long)__float_as_uint(lds_in(7, owner)) |
@@ -1017,7 +1082,6 @@ struct Tracer {
         }
       }
       wave_sync();  // the results are consumed: the next chunk / the next shared phase may overwrite them
-      if (!kChunkedAO) break;
     }
     return ao;
   }
