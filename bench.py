@@ -112,6 +112,69 @@ def load_traffic(path):
     return j.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this build ({os.path.basename(path)})"
 
 
+def animated_volume_leg(local_rank, vox, vres, opts, mc, n, width, contract, frames=12):
+    """A NEW volume every frame (the reference's heat-map animation, meshvoxel.clj:85-89 -> core.clj:181-213): the frame
+    period when the tables of volume k+1 are built on the library's own stream beside frame k (rm_stage_volume_device /
+    rm_commit_staged_volume), next to the serial form (rm_set_volume_device, tables inside the frame).  Blocking frames:
+    the caller waits for frame k before it commits volume k+1.  Inputs resident in HBM; never `value`."""
+    import torch
+
+    from raymarchcl_amd import _native
+
+    dev = torch.device("cuda", local_rank)
+    res = vres[0]
+    base = torch.from_numpy(np.ascontiguousarray(vox)).to(dev).reshape(res, res, res)
+    vols = [torch.roll(base, shifts=5 * k, dims=k % 3).contiguous().reshape(-1) for k in range(3)]  # three different volumes
+    iters = len(opts) // 544
+    d_opts = torch.from_numpy(np.frombuffer(opts, dtype=np.uint8).copy()).to(dev)
+    d_mc = torch.from_numpy(np.ascontiguousarray(mc, dtype=np.float32)).to(dev)
+    d_px = torch.zeros(4 * n, dtype=torch.float32, device=dev)
+    d_argb = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    iso = 32
+    with _native.Context(local_rank, contract=contract) as ctx:
+        def frame():
+            ctx.frame_device_full(d_opts.data_ptr(), d_mc.data_ptr(), iters, n, width, d_px.data_ptr(), d_argb.data_ptr())
+
+        # serial: the volume changes, the next frame builds its tables
+        ctx.set_volume_device(vols[0].data_ptr(), vres)
+        ctx.check_device_opts(d_opts.data_ptr(), iters, n, width)
+        frame()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            ctx.set_volume_device(vols[(k + 1) % 3].data_ptr(), vres)
+            ctx.check_device_opts(d_opts.data_ptr(), iters, n, width)  # (builds the tables)
+            frame()
+            ctx.synchronize()
+        serial_ms = (time.perf_counter() - t0) / frames * 1e3
+        build_ms = ctx.last_table_build_ms()
+        # staged: tables of volume k+1 beside frame k
+        ctx.stage_volume_device(vols[0].data_ptr(), vres, iso)
+        ctx.commit_staged_volume()
+        ctx.check_device_opts(d_opts.data_ptr(), iters, n, width)
+        frame()
+        ctx.stage_volume_device(vols[1].data_ptr(), vres, iso)
+        ctx.synchronize()
+        ctx.commit_staged_volume()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            frame()
+            ctx.stage_volume_device(vols[(k + 2) % 3].data_ptr(), vres, iso)
+            ctx.synchronize()
+            ctx.commit_staged_volume()
+        staged_ms = (time.perf_counter() - t0) / frames * 1e3
+        hist = ctx.frame_timing_history(frames)
+        kernel_beside_build = float(np.mean([ms / k for ms, k in hist]))
+        staged_build_ms = ctx.last_table_build_ms()
+    return {"frame_period_ms_staged": round(staged_ms, 4), "frame_period_ms_serial": round(serial_ms, 4),
+            "kernel_ms_beside_the_build": round(kernel_beside_build, 4), "table_build_ms_alone": round(build_ms, 3),
+            "table_build_ms_beside_the_frame": round(staged_build_ms, 3), "frames": frames,
+            "note": "a different volume every frame, blocking frames, inputs resident in HBM: staged = "
+                    "rm_stage_volume_device(volume k+1) right after the launch of frame k, rm_commit_staged_volume after the "
+                    "wait; serial = rm_set_volume_device + rm_check_device_opts (tables built before the frame's launch)"}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line under
     torch.distributed.run with one rank per GPU (rank 0 prints the JSON line)."""
@@ -376,6 +439,8 @@ def main():
             tp = time.perf_counter()
             hctx.render_frame(opts, mc, n)  # the first frame of a fresh context builds the tables
             first_ms = (time.perf_counter() - tp) * 1e3
+            if args.workload == "c2":
+                out["animated_volume"] = animated_volume_leg(local_rank, vox, vres, opts, mc, n, width, args.contract)
             out["precompute"] = {"derived_tables_ms": round(hctx.last_table_build_ms(), 3),
                                  "first_frame_ms": round(first_ms, 3),
                                  "note": "dist8 + oct8 + surf32 of the resident volume (device time, HIP events), built "

@@ -151,11 +151,20 @@ __global__ __launch_bounds__(256) void unbrick_kernel(const uint8_t* __restrict_
 
 constexpr int kOctTile = 16;
 constexpr int kOctLds = kOctTile + 1;  // + the layer of cells ahead of the tile (u - 1)
+// LDS layout of a tile: PLANE-MAJOR.  The sweep handles one plane la + lb + lc = t per step, one cell per thread; with the
+// tile stored as s[lc][lb][la] the threads of a wavefront read addresses 272-288 bytes apart -- four LDS banks for all
+// of them -- and a step took ~700 cycles.  Stored as s[t][lb][la] (t = la + lb + lc, every plane a dense 17 x 17 array)
+// the cells of a step are consecutive bytes, and the seven neighbours ahead sit at fixed offsets in the planes t-1 .. t-3.
+constexpr int kOctPlane = kOctLds * kOctLds;            // bytes per plane
+constexpr int kOctPlanes = 3 * kOctLds - 2;             // t + 3 for la, lb, lc in [-1, 15]
+__device__ __forceinline__ int oct_lds_index(int la, int lb, int lc) {
+  return (la + lb + lc + 3) * kOctPlane + (lb + 1) * kOctLds + (la + 1);
+}
 __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
                                                        uint8_t* __restrict__ out8, int k, int a_lo, int nb, int nc,
                                                        long long table_bytes, int bricked) {
   // the tile and the layer of cells ahead of it, in u-space: s[lc + 1][lb + 1][la + 1]
-  __shared__ uint8_t s[kOctLds * kOctLds * kOctLds];
+  __shared__ uint8_t s[kOctPlanes * kOctPlane];
   const int o = blockIdx.y;                       // octant
   const bool nx = o & 1, ny = o & 2, nz = o & 4;  // bit set: walking towards the low face
   // tile (A, B, C) of this block on the tile diagonal A + B + C = k
@@ -165,7 +174,46 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
   uint8_t* __restrict__ tab = out8 + (long long)o * table_bytes;
   const int a0 = A * kOctTile, b0 = B * kOctTile, c0 = C * kOctTile;
   // fill: tile cells get 255 (empty, edge unknown) or 0 (hit, or behind the grid's far face);
-  // the layer ahead gets the finished values of the neighbouring tiles, 0 beyond the grid
+  // the layer ahead gets the finished values of the neighbouring tiles, 0 beyond the grid.
+  // (Round 6: a launch of this kernel is as long as ONE tile takes -- the tile diagonals are a chain of 3R/16 launches --
+  //  and a tile took ~20 us, most of it in this fill: 20 global byte loads per thread, each issued after the previous one
+  //  had arrived.  Now a thread fetches its row of 16 voxels with ONE 16-byte load and at most four halo bytes, all
+  //  independent; rows of 16 cells are contiguous and aligned when the row length is a multiple of 16.)
+  const bool rows16 = (d.rx & 15) == 0 && (reinterpret_cast<unsigned long long>(vox) & 15ull) == 0;  // (a borrowed volume may sit anywhere)
+  if (rows16) {
+    const int rb = threadIdx.x & (kOctTile - 1), rc = threadIdx.x >> 4;  // this thread's row of the tile
+    const int b = b0 + rb, c = c0 + rc;
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    const bool row_ok = b < d.ry && c < d.rz;  // (a0 + 15 < rx: the row length is a multiple of the tile edge)
+    const int y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
+    const int xs = nx ? a0 : d.rx - kOctTile - a0;  // lowest x of the row
+    if (row_ok) q = *reinterpret_cast<const uint4*>(vox + (long long)z * sz + (long long)y * sy + xs);
+    // the halo: la = -1 (17 x 17 cells), lb = -1 with la >= 0 (16 x 17), lc = -1 with la, lb >= 0 (16 x 16): 817 cells
+    uint8_t hv[4];
+    int hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int h = (int)threadIdx.x + 256 * r;
+      int la, lb, lc;
+      if (h < 289) { la = -1; lb = h % 17 - 1; lc = h / 17 - 1; }
+      else if (h < 561) { const int g = h - 289; la = g & 15; lb = -1; lc = g / 16 - 1; }
+      else { const int g = h - 561; la = g & 15; lb = (g >> 4) & 15; lc = -1; }
+      const int a = a0 + la, bb = b0 + lb, cc = c0 + lc;
+      const bool ok = h < 817 && a >= 0 && bb >= 0 && cc >= 0 && a < d.rx && bb < d.ry && cc < d.rz;
+      const int x = nx ? a : d.rx - 1 - a, yy = ny ? bb : d.ry - 1 - bb, zz = nz ? cc : d.rz - 1 - cc;
+      hv[r] = ok ? tab[tab_index(d, x, yy, zz, bricked)] : (uint8_t)0;  // finished by an earlier launch
+      hi[r] = h < 817 ? oct_lds_index(la, lb, lc) : -1;
+    }
+    const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int jx = 0; jx < kOctTile; jx++) {
+      const int v = (int)((qw[jx >> 2] >> (8 * (jx & 3))) & 0xffu);
+      s[oct_lds_index(nx ? jx : kOctTile - 1 - jx, rb, rc)] = (row_ok && v <= iso) ? 255 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (hi[r] >= 0) s[hi[r]] = hv[r];
+  } else {
   for (int i = threadIdx.x; i < kOctLds * kOctLds * kOctLds; i += 256) {
     const int la = i % kOctLds - 1, lb = (i / kOctLds) % kOctLds - 1, lc = i / (kOctLds * kOctLds) - 1;
     const int a = a0 + la, b = b0 + lb, c = c0 + lc;  // u
@@ -175,16 +223,18 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
       if (la < 0 || lb < 0 || lc < 0) v = tab[tab_index(d, x, y, z, bricked)];  // finished by an earlier launch
       else v = vox[(long long)z * sz + (long long)y * sy + x] <= iso ? 255 : 0;
     }
-    s[i] = v;
+    s[oct_lds_index(la, lb, lc)] = v;
+  }
   }
   __syncthreads();
   const int la = threadIdx.x & (kOctTile - 1), lb = threadIdx.x >> 4;
   for (int t = 0; t < 3 * kOctTile - 2; t++) {
     const int lc = t - la - lb;
     if (lc >= 0 && lc < kOctTile) {
-      const int i = ((lc + 1) * kOctLds + (lb + 1)) * kOctLds + (la + 1);
+      const int i = oct_lds_index(la, lb, lc);
       if (s[i]) {
-        const int e1 = 1, e2 = kOctLds, e3 = kOctLds * kOctLds;
+        // one step back along an axis = one plane back (and one byte / one row back for la / lb)
+        const int e1 = kOctPlane + 1, e2 = kOctPlane + kOctLds, e3 = kOctPlane;
         int m = s[i - e1];
         m = min(m, (int)s[i - e2]);
         m = min(m, (int)s[i - e3]);
@@ -197,12 +247,31 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
     }
     __syncthreads();
   }
+  if (rows16) {  // a thread stores its row: 16 bytes, contiguous in a row-major table, two runs of 8 in a bricked one
+    const int rb = threadIdx.x & (kOctTile - 1), rc = threadIdx.x >> 4;
+    const int b = b0 + rb, c = c0 + rc;
+    if (b < d.ry && c < d.rz) {
+      const int y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
+      const int xs = nx ? a0 : d.rx - kOctTile - a0;
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int jx = 0; jx < kOctTile; jx++)  // byte jx of the run = cell x = xs + jx
+        w[jx >> 2] |= (uint32_t)s[oct_lds_index(nx ? jx : kOctTile - 1 - jx, rb, rc)] << (8 * (jx & 3));
+      if (!bricked) {
+        *reinterpret_cast<uint4*>(tab + tab_index(d, xs, y, z, 0)) = make_uint4(w[0], w[1], w[2], w[3]);
+      } else {
+        *reinterpret_cast<uint2*>(tab + tab_index(d, xs, y, z, 1)) = make_uint2(w[0], w[1]);
+        *reinterpret_cast<uint2*>(tab + tab_index(d, xs + 8, y, z, 1)) = make_uint2(w[2], w[3]);
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < kOctTile * kOctTile * kOctTile; i += 256) {
     const int la2 = i & (kOctTile - 1), lb2 = (i >> 4) & (kOctTile - 1), lc2 = i >> 8;
     const int a = a0 + la2, b = b0 + lb2, c = c0 + lc2;
     if (a < d.rx && b < d.ry && c < d.rz) {
       const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
-      tab[tab_index(d, x, y, z, bricked)] = s[((lc2 + 1) * kOctLds + (lb2 + 1)) * kOctLds + (la2 + 1)];
+      tab[tab_index(d, x, y, z, bricked)] = s[oct_lds_index(la2, lb2, lc2)];
     }
   }
 }

@@ -91,6 +91,13 @@ struct rm_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::shared_ptr<Volume> vol;
+  // rm_stage_volume_device: the NEXT volume, whose derived tables are built on prep_stream while the resident one renders
+  std::shared_ptr<Volume> staged;
+  hipStream_t prep_stream = nullptr;
+  hipEvent_t ev_staged = nullptr;     // prep_stream: the staged volume's tables are complete
+  hipEvent_t ev_back_free = nullptr;  // stream: every frame that read the volume retired by the last commit has been enqueued before it
+  hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr;  // timed: the staged build
+  bool staged_ready = false, back_free_pending = false, staged_timing = false;
   DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, sdfq_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
@@ -186,53 +193,67 @@ int check_frame_opts(rm_ctx* c, const RmOpts* recs, int iter, int n, int width) 
   return RM_OK;
 }
 
+// can this volume have derived tables at all (walk_step's index arithmetic)?
+static bool tables_possible(const rm_ctx* c, const Volume& v) {
+  if (!c->use_accel) return false;
+  // walk_step indexes with 24-bit multiplies: fall back to the plain march otherwise
+  if ((long long)v.ry * v.rz >= (1 << 24) || v.rx >= (1 << 24)) return false;
+  return (size_t)v.rx * v.ry * v.rz < ((size_t)1 << 31);  // the kernels hold a cell index in an int
+}
+
+// Enqueue the build of dist8 / oct8 / surf32 of `v` for hit threshold `iso` on stream `st`, bracketed by the timed events
+// t0 / t1.  No host synchronisation: the caller decides who may see the tables when (ensure_accel waits; a staged
+// volume -- rm_stage_volume_device -- hands an event to the stream that will render it).
+static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
+  const size_t vox = (size_t)v.rx * v.ry * v.rz;
+  // directional tables behind dist8 (measured -10 % frame time at 256^3, -12 % at 512^3 with
+  // 8 % fill); table offsets are 64-bit, nine 1024^3 tables span 9 GiB
+  const bool oct = c->use_octants;
+  const int tables = oct ? 9 : 1;
+  // Row-major tables have the cheapest index arithmetic and win while the Infinity Cache
+  // catches most misses (bricks: +1..3 % at 256^3); beyond it misses go to HBM and locality wins: 1024^3
+  // -6.6 % (layout 1), 512^3 -2.5 % with the brick number formed by shifts (layout 3, round 4; with layout 1's
+  // multiplies and 64-bit offsets it had been a draw)
+  const bool cube512 = v.rx == 512 && v.ry == 512 && v.rz == 512 && c->pow2_tables;
+  const bool bricked = oct &&
+                       (c->bricks >= 0 ? c->bricks == 1 : (vox * 13 > ((size_t)4 << 30) || cube512));
+  const size_t tbytes = bricked ? (size_t)rmk::bricked_bytes(v.rx, v.ry, v.rz) : vox;
+  HIP_TRY(v.dist_buf.reserve(tbytes * tables));
+  uint8_t* lin = static_cast<uint8_t*>(v.dist_buf.p);
+  HIP_TRY(v.surf_buf.reserve(vox * 4));
+  HIP_TRY(hipEventRecord(t0, st));
+  v.oct_stride = 0;
+  if (oct) {
+    HIP_TRY(rmk::build_accel(st, v.d_vox, v.rx, v.ry, v.rz, iso, nullptr, nullptr,
+                             static_cast<uint32_t*>(v.surf_buf.p)));
+    HIP_TRY(rmk::build_octants(st, v.d_vox, v.rx, v.ry, v.rz, iso, lin, bricked));
+    v.oct_stride = tbytes;
+    v.bricked = bricked;
+  } else {
+    v.bricked = false;
+    HIP_TRY(v.tmp_buf.reserve(vox));
+    HIP_TRY(rmk::build_accel(st, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
+                             static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
+  }
+  HIP_TRY(hipEventRecord(t1, st));
+  return RM_OK;
+}
+
 // Build (or reuse) dist8 / oct8 / surf32 for the hit threshold of this launch.
 int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   *out = rmk::Accel{};
-  if (!c->use_accel) return RM_OK;
   Volume& v = *c->vol;
-  // walk_step indexes with 24-bit multiplies: fall back to the plain march otherwise
-  if ((long long)v.ry * v.rz >= (1 << 24) || v.rx >= (1 << 24)) return RM_OK;
+  if (!tables_possible(c, v)) return RM_OK;
   const size_t vox = (size_t)v.rx * v.ry * v.rz;
-  if (vox >= ((size_t)1 << 31)) return RM_OK;  // the kernels hold a cell index in an int
   std::lock_guard<std::mutex> lock(v.mu);
   if (v.accel_iso != iso) {
-    // directional tables behind dist8 (measured -10 % frame time at 256^3, -12 % at 512^3 with
-    // 8 % fill); table offsets are 64-bit, nine 1024^3 tables span 9 GiB
-    const bool oct = c->use_octants;
-    const int tables = oct ? 9 : 1;
-    // Row-major tables have the cheapest index arithmetic and win while the Infinity Cache
-    // catches most misses (bricks: +1..3 % at 256^3); beyond it misses go to HBM and locality wins: 1024^3
-    // -6.6 % (layout 1), 512^3 -2.5 % with the brick number formed by shifts (layout 3, round 4; with layout 1's
-    // multiplies and 64-bit offsets it had been a draw)
-    const bool cube512 = v.rx == 512 && v.ry == 512 && v.rz == 512 && c->pow2_tables;
-    const bool bricked = oct &&
-                         (c->bricks >= 0 ? c->bricks == 1 : (vox * 13 > ((size_t)4 << 30) || cube512));
-    const size_t tbytes = bricked ? (size_t)rmk::bricked_bytes(v.rx, v.ry, v.rz) : vox;
-    hipEvent_t t0 = c->ev_b0, t1 = c->ev_b1;
-    HIP_TRY(v.dist_buf.reserve(tbytes * tables));
-    uint8_t* lin = static_cast<uint8_t*>(v.dist_buf.p);
-    HIP_TRY(v.surf_buf.reserve(vox * 4));
-    HIP_TRY(hipEventRecord(t0, c->stream));
-    v.oct_stride = 0;
-    if (oct) {
-      HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, nullptr, nullptr,
-                               static_cast<uint32_t*>(v.surf_buf.p)));
-      HIP_TRY(rmk::build_octants(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin, bricked));
-      v.oct_stride = tbytes;
-      v.bricked = bricked;
-    } else {
-      v.bricked = false;
-      HIP_TRY(v.tmp_buf.reserve(vox));
-      HIP_TRY(rmk::build_accel(c->stream, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
-                               static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
-    }
-    HIP_TRY(hipEventRecord(t1, c->stream));
+    int rc = enqueue_tables(c, v, iso, c->stream, c->ev_b0, c->ev_b1);
+    if (rc) return rc;
     // contexts that share the volume run on other streams: the tables are complete before
     // anybody else can see accel_iso
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventElapsedTime(&ms, c->ev_b0, c->ev_b1);
     v.accel_build_ms = ms;
     v.accel_iso = iso;
   }
@@ -551,6 +572,19 @@ static int create_one(int device_id, rm_ctx** out) {
   if (e == hipSuccess) e = hipEventCreate(&c->ev_resolved);  // (timed: rm_last_frame_breakdown)
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_b1);
+  if (e == hipSuccess) {
+    // the staged build is a chain of ~50 short dependent launches: at the frame kernel's priority each of them queues
+    // behind a machine full of frame wavefronts and the chain ends 2 ms AFTER the frame (measured: no overlap at all);
+    // at the highest priority its workgroups take the slots that retiring frame wavefronts free
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char* pp = getenv("RAYMARCH_PREP_PRIORITY");  // (A/B: 0 = the frame kernel's priority)
+    e = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, (pp && pp[0] == '0') ? 0 : hi);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_back_free, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_s0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_s1);
   if (e != hipSuccess) {
     rm_destroy(c);
     return fail(RM_EDEVICE, "stream/event creation: %s", hipGetErrorString(e));
@@ -647,6 +681,10 @@ void rm_destroy(rm_ctx* c) {
   if (c->ev_resolved) (void)hipEventDestroy(c->ev_resolved);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
   if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
+  if (c->prep_stream) { (void)hipStreamSynchronize(c->prep_stream); (void)hipStreamDestroy(c->prep_stream); }
+  c->staged.reset();
+  for (hipEvent_t ev : {c->ev_staged, c->ev_back_free, c->ev_s0, c->ev_s1})
+    if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -789,6 +827,71 @@ int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz
   return broadcast_volume(c);
 }
 
+// ---- animated volumes: the next volume's tables are built while the resident one renders (meshvoxel.clj:85-89
+// make-heatmap-anim feeds core.clj:181-213 a new volume per frame; built inside the frame they cost 2.25 ms per 256^3
+// volume on top of a 4 ms frame).  Two volume states per context: `vol` (resident, rendered from) and `staged`.
+int rm_stage_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz, int iso_val) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!d_voxels) return fail(RM_EINVAL, "d_voxels is NULL");
+  if (iso_val < 0 || iso_val > 255) return fail(RM_EINVAL, "iso_val = %d", iso_val);
+  rc = check_res(rx, ry, rz);
+  if (rc) return rc;
+  if (!c->peers.empty() || c->parent)
+    return fail(RM_ESTATE, "rm_stage_volume_device: not on a multi-device context (rm_set_volume_device replicates there)");
+  // the slot: the volume the last commit retired, if nobody else still renders from it
+  if (!c->staged || c->staged.use_count() != 1) {
+    Volume* v = new (std::nothrow) Volume();
+    if (!v) return fail(RM_EDEVICE, "out of host memory");
+    v->device = c->device;
+    c->staged.reset(v);
+  }
+  c->staged_ready = false;
+  Volume& v = *c->staged;
+  std::lock_guard<std::mutex> lock(v.mu);
+  static std::atomic<unsigned long long> next_staged_generation{1ull << 48};
+  v.generation = next_staged_generation.fetch_add(1);
+  v.accel_iso = -1;
+  v.d_vox = static_cast<const uint8_t*>(d_voxels);
+  v.rx = rx; v.ry = ry; v.rz = rz;
+  // frames that still read the retired volume's tables were enqueued on the context's stream before ev_back_free
+  if (c->back_free_pending) HIP_TRY(hipStreamWaitEvent(c->prep_stream, c->ev_back_free, 0));
+  c->back_free_pending = false;
+  if (tables_possible(c, v)) {
+    rc = enqueue_tables(c, v, iso_val, c->prep_stream, c->ev_s0, c->ev_s1);
+    if (rc) { v.d_vox = nullptr; return rc; }
+    v.accel_iso = iso_val;  // (visible to the context's stream behind ev_staged only: rm_commit_staged_volume)
+    c->staged_timing = true;
+  }
+  HIP_TRY(hipEventRecord(c->ev_staged, c->prep_stream));
+  c->staged_ready = true;
+  return RM_OK;
+}
+
+int rm_commit_staged_volume(rm_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->staged || !c->staged_ready) return fail(RM_ESTATE, "rm_commit_staged_volume: no volume has been staged");
+  // everything enqueued so far may read the volume that retires now ...
+  HIP_TRY(hipEventRecord(c->ev_back_free, c->stream));
+  c->back_free_pending = true;
+  // ... and everything enqueued from here on sees the staged tables complete
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_staged, 0));
+  const bool same_shape = c->vol && c->vol->rx == c->staged->rx && c->vol->ry == c->staged->ry && c->vol->rz == c->staged->rz;
+  const bool validated = same_shape && c->dev_src && c->dev_generation == c->vol->generation;
+  std::swap(c->vol, c->staged);
+  c->staged_ready = false;
+  if (validated) {
+    // what rm_check_device_opts checked (resolution, voxelRes against the volume, numLights) does not depend on the
+    // volume's bytes: the records stay accepted for a volume of the same shape
+    c->dev_generation = c->vol->generation;
+  } else {
+    c->dev_src = nullptr;
+    c->dev_recs.clear();
+  }
+  return RM_OK;
+}
+
 int rm_invalidate_volume(rm_ctx* c) {
   int rc = check_ctx(c);
   if (rc) return rc;
@@ -808,6 +911,8 @@ int rm_share_volume(rm_ctx* dst, rm_ctx* src) {
   if (src->device != dst->device)
     return fail(RM_EINVAL, "rm_share_volume: contexts are on devices %d and %d", src->device, dst->device);
   if (!dst->peers.empty() || dst->parent) return fail(RM_EINVAL, "rm_share_volume: multi-device context");
+  // (a volume committed from the staging slot: its tables are ordered behind src's stream only -- complete them for everybody)
+  if (src->ev_staged) HIP_TRY(hipEventSynchronize(src->ev_staged));
   dst->vol = src->vol;
   dst->dev_src = nullptr;
   dst->dev_recs.clear();
@@ -1353,6 +1458,13 @@ int rm_last_table_build_ms(rm_ctx* c, float* ms) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (!have_volume(c) || c->vol->accel_iso < 0) return fail(RM_ESTATE, "no derived tables have been built");
+  if (c->staged_timing) {  // the last build was a staged one: its events are read here, not where it was enqueued
+    HIP_TRY(hipEventSynchronize(c->ev_s1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev_s0, c->ev_s1));
+    (c->staged_ready ? c->staged : c->vol)->accel_build_ms = t;
+    c->staged_timing = false;
+  }
   if (ms) *ms = (float)c->vol->accel_build_ms;
   return RM_OK;
 }
