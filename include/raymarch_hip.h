@@ -349,8 +349,9 @@ int rm_debug_get_octants(rm_ctx* ctx, int iso, uint8_t* oct_out);
  * dispatches FIRST: the rows in which the clip box [voxelBoundsMin, voxelBoundsMax] of the 544-byte record `opts`
  * covers at least half as much of the image's width as in the row where it covers most -- the box's edges through the
  * inverse of cameraRayLookat (renderer.cl:456-465).  A scheduling heuristic (longest jobs first; then the rows below
- * the band, the rows above it -- sky -- as the tail of a blocking frame; RAYMARCH_ROW_ORDER=desc|asc switch it off):
- * pixels never depend on it.  Host-side, no device needed. */
+ * the band, the rows above it -- sky -- as the tail of a blocking frame), OPT-IN with RAYMARCH_ROW_ORDER=band: at
+ * BASELINE's camera the box fills the view and there is no band; at farther cameras it measured -1.9 .. +3.5 %.
+ * The default order is plain bottom to top.  Pixels never depend on it.  Host-side, no device needed. */
 int rm_debug_volume_band(const void* opts, double* lo, double* hi);
 
 /* ---- host-side parameter layer (no device needed) ------------------------

@@ -103,7 +103,9 @@ struct rm_ctx {
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
   bool rows_desc = true;     // RAYMARCH_ROW_ORDER=asc: tile rows top to bottom (rounds 2-4); default bottom to top
-  bool rows_band = true;     // ... with the rows that can see the clip box first (round 6); RAYMARCH_ROW_ORDER=desc: plain bottom to top
+  bool rows_band = false;    // RAYMARCH_ROW_ORDER=band: the rows where the clip box covers most of the width first (volume_band,
+                             // round 6).  Opt-in: no band exists at BASELINE's camera (the box fills the view), and at three
+                             // farther cameras it measured -1.9 % / -0.3 % / +3.5 % (profiles/r06_experiments.txt)
   double band_fixed_lo = 0.0, band_fixed_hi = 0.0;  // RAYMARCH_ROW_BAND=lo,hi (fractions of the image height): that band instead
   int pass_pack = 4;         // RAYMARCH_PASS_PACK (0..6): log2 of the passes one wavefront holds at most.  Default 4 =
                              // 4 pixels x 16 passes, measured best for full groups (64 passes as 4 x 16 / 2 x 32 / 1 x 64:
@@ -603,7 +605,7 @@ static int create_one(int device_id, rm_ctx** out) {
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* ro = getenv("RAYMARCH_ROW_ORDER");
   if (ro) c->rows_desc = !(ro[0] == 'a');
-  if (ro) c->rows_band = ro[0] == 'b';  // "band" (default) / "desc" / "asc"
+  if (ro) c->rows_band = ro[0] == 'b';  // "desc" (default) / "band" / "asc"
   if (const char* rb = getenv("RAYMARCH_ROW_BAND")) (void)sscanf(rb, "%lf,%lf", &c->band_fixed_lo, &c->band_fixed_hi);
   const char* pk = getenv("RAYMARCH_PASS_PACK");
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) { c->pass_pack = atoi(pk); c->pass_pack_auto = false; }
