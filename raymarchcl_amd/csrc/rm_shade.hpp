@@ -11,12 +11,6 @@
 // (shade_wave()).  rm_kernels.hip wraps both in the kernels.
 #pragma once
 #include "rm_math.hpp"
-#ifndef RM_BIN_SHADOW
-#define RM_BIN_SHADOW 0  // experiment switches of round 6 (profiles/r06_experiments.txt): product = 0
-#endif
-#ifndef RM_PARK_LDS
-#define RM_PARK_LDS 0
-#endif
 #include "rm_opts.h"
 
 namespace rmk {
@@ -639,7 +633,11 @@ struct Tracer {
   // could no longer change it (walk_limit_for)
   // unit_dir: rdir comes straight out of normalize() (camera rays, light directions): its length is 1 to a few ulps, so
   // the walk limits -- bounds whose direction of error alone matters -- take 0.9999 for it and the samples per unit
-  // become a launch-uniform number held in a scalar register (reflected directions are not unit vectors: measured there)
+  // become a launch-uniform number held in a scalar register (reflected directions are not unit vectors: measured there).
+  // (normalize() of the contract's library returns a unit vector for EVERY finite non-zero input -- it rescales inputs whose
+  //  squared length would underflow or overflow --; for a zero or NaN input it returns zero / NaN, and then every sample of
+  //  a walk lies in the cell of the first one (or nowhere): a walk cut short ends as the whole one would.  Lights inside
+  //  the volume, on the ground plane and at 1e30: tests/test_gpu_parity.py test_walk_limits_with_unusual_records.)
   RM_DEV void march(v3 ro, v3 rdir, Hit& r, float maxDist, int maxSteps, bool smooth,
                     bool distance_only = false, bool unit_dir = false) {
     const RmOpts& o = *sc.o;
@@ -1095,7 +1093,7 @@ struct Tracer {
   // the shadow marches of lighting() for all lanes: distance reached by the march towards
   // light i in lds_res(i, lane) (only where the light passes the attenuation test)
   // `need`: bit i set = this lane owns a hit whose light i needs its shadow march (lighting_wave)
-  RM_DEV void shadows_wave(unsigned int need, v3 hitpos, v3 jit, unsigned int long_bits = 0u) {
+  RM_DEV void shadows_wave(unsigned int need, v3 hitpos, v3 jit) {
     const RmOpts& o = *sc.o;
     const int nl = o.numLights;
     const bool active = need != 0u;
@@ -1108,24 +1106,12 @@ struct Tracer {
     // the task list, light-major: one byte (light << 6 | owner lane) per needed (owner, light) pair
     uint8_t* const task_of = reinterpret_cast<uint8_t*>(&lds_map(0));
     int tasks = 0;
-#if RM_BIN_SHADOW
-    // (experiment, round 6: the tasks expected to march longest first, so that a phase of several rounds ends with a
-    //  round of short marches; long_bits from lighting_wave)
-    for (int b = 1; b >= 0; b--)
-      for (int i = 0; i < nl && i < 4; i++) {  // uniform
-        const bool mine = ((need >> i) & 1u) && (int)((long_bits >> i) & 1u) == b;
-        const unsigned long long mk = __ballot(mine);
-        if (mine) task_of[tasks + __popcll(mk & ((1ull << dl.lane) - 1ull))] = (uint8_t)((i << 6) | dl.lane);
-        tasks += __popcll(mk);
-      }
-#else
     for (int i = 0; i < nl && i < 4; i++) {  // uniform
       const bool mine = (need >> i) & 1u;
       const unsigned long long mk = __ballot(mine);
       if (mine) task_of[tasks + __popcll(mk & ((1ull << dl.lane) - 1ull))] = (uint8_t)((i << 6) | dl.lane);
       tasks += __popcll(mk);
     }
-#endif
     wave_sync();
     for (int base = 0; base < tasks; base += dl.helpers) {
       const int t = base + dl.my_slot;
@@ -1160,13 +1146,6 @@ struct Tracer {
     const RmOpts& o = *sc.o;
     if (__ballot(active) == 0) return V(0.f, 0.f, 0.f);  // uniform
     const float ao = occlusion_wave(active, s, hitpos, normal);
-#if RM_PARK_LDS
-    if (active) {  // (occlusion_wave posted them in this lane's own column)
-      const int me = (int)(threadIdx.x & 63);
-      hitpos = V(lds_in(0, me), lds_in(1, me), lds_in(2, me));
-      normal = V(lds_in(3, me), lds_in(4, me), lds_in(5, me));
-    }
-#endif
     // light jitter: one table value for all lights (renderer.cl:263-269)
     v3 jit = V(0.f, 0.f, 0.f);
     if (active) {
@@ -1182,7 +1161,7 @@ struct Tracer {
     // all of those have a clear sign bit (and are not NaN) they never hold -0: the shadow
     // term of such a pair cannot reach the result and its march -- about a quarter of all
     // shadow marches -- is not traced.  (4 lights at most, the size of the record's arrays.)
-    unsigned int need = 0u, long_bits = 0u;
+    unsigned int need = 0u;
     if (active) {
       const Material m = material(objectID);
       const v3 rc = mirror_sky ? sky(reflect(raydir, normal)) : reflectCol;
@@ -1199,29 +1178,11 @@ struct Tracer {
           clean &= finite_nonneg(inc);
           const bool back = M::fmax(0.0f, dot(ldir, normal)) == 0.0f;
           if (back && !(dot(normalize(ldir - raydir), normal) > 0.0f)) dark |= 1u << i;
-#if RM_BIN_SHADOW == 1   // grazing light directions creep along the surface
-          if (dot(ldir, normal) < 0.35f) long_bits |= 1u << i;
-#elif RM_BIN_SHADOW == 2 // starts inside the clip box (the others leave after filtered turns only)
-          if (fmaxf(fmaxf(__builtin_fabsf(hitpos.x), __builtin_fabsf(hitpos.y)), __builtin_fabsf(hitpos.z)) < 0.99f) long_bits |= 1u << i;
-#elif RM_BIN_SHADOW == 3 // low start and a flat light direction: the ground term grows slowly
-          if ((hitpos.y + o.groundY) < 0.5f && ldir.y < 0.4f) long_bits |= 1u << i;
-#elif RM_BIN_SHADOW == 4 // far lights
-          if (att < 0.12f) long_bits |= 1u << i;
-#endif
         }
       }
       if (clean) need &= ~dark;
     }
-    shadows_wave(need, hitpos, jit, long_bits);
-#if RM_PARK_LDS
-    // (experiment, round 6: a lane's own column of the exchange area still holds what it posted -- nobody else writes
-    //  there --: take hit position and light jitter back from it, so that they need no register across the phase)
-    if (active) {
-      const int me = (int)(threadIdx.x & 63);
-      hitpos = V(lds_in(0, me), lds_in(1, me), lds_in(2, me));
-      jit = V(lds_in(3, me), lds_in(4, me), lds_in(5, me));
-    }
-#endif
+    shadows_wave(need, hitpos, jit);
     v3 res = V(0.f, 0.f, 0.f);
     if (active) {
       const Material m = material(objectID);

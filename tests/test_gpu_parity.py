@@ -299,6 +299,12 @@ def test_shared_secondary_rays_against_oracle(oracle_mod, native, name, over):
     ("max_dist_short", dict(maxDist=2.0)),               # marches end on distance inside the scene
     ("few_turns", dict(maxIter=6, shadowIter=3)),        # marches run out of turns
     ("start_dist", dict(startDist=0.7)),
+    # degenerate light vectors (round-5 ADVICE: marches along light directions take |dir| = 1 for their walk limits):
+    # a light inside the volume without jitter (hits a few voxels from it: tiny, exactly representable offsets), a light
+    # so far that 1/d^2 underflows (no march at all), and one whose distance overflows to inf
+    ("light_inside_no_jitter", dict(lightScatter=0.0, lightPos=[[0.0, 0.0, 0.0, 0], [0.25, -0.5, 0.25, 0]])),
+    ("light_on_the_ground_plane", dict(lightScatter=0.0, lightPos=[[0.5, -1.05, 0.5, 0], [-0.5, -1.05, 0.25, 0]])),
+    ("light_at_1e30", dict(lightPos=[[1e30, 0.0, 0.0, 0], [0.0, 3e19, 0.0, 0]])),
     ("anisotropic_scale", dict(invVoxelScale=[0.5, 0.4, 0.625], voxelBounds=[1.0, 1.25, 0.8],
                                voxelBounds2=[2.0, 2.5, 1.6], voxelBoundsMin=[-0.99, -1.2375, -0.792],
                                voxelBoundsMax=[0.99, 1.2375, 0.792])),
