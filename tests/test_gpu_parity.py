@@ -370,7 +370,7 @@ def test_tables_beyond_4_gib(native, oracle_mod):
 
 def test_randomised_parity_smoke():
     """A short run of tools/fuzz_parity.py (random cameras, presets, volumes, record overrides);
-    the long runs are recorded in profiles/r01_fuzz_parity.txt."""
+    the long runs are recorded in profiles/archive_r01.txt (FILE r01_fuzz_parity.txt)."""
     import importlib.util
     import os
 

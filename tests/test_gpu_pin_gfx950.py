@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 import scenes
+from gfx950_pin import fast_ref, pin_default  # noqa: F401  (fixtures: the `fast` yardstick, the checker of the default contract)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_contract")]  # this module checks against the CPU oracle
 
@@ -100,7 +101,7 @@ def test_metric_against_every_reference_build(rendered, refs):
         frac, frac_stable = (r <= 1e-4).mean(), (r[stable] <= 1e-4).mean()
         print(f"{name}: HIP gpu-cast vs `{b}`: {100 * frac:.3f} % within 1e-4 ({100 * frac_stable:.3f} % of the stable "
               f"pixels; reference builds among themselves: {100 * among:.3f} %)")
-        # measured (profiles/r03_pin_gfx950.txt, unchanged since): 96.6-98 % of all pixels, 97.4-99 % of the stable ones
+        # measured (profiles/archive_r03.txt FILE r03_pin_gfx950.txt, unchanged since): 96.6-98 % of all pixels, 97.4-99 % of the stable ones
         # -- the x86-strict arithmetic of this path (unfused mad, IEEE normalize, its own exp/pow)
         # against ocml's; the reference builds agree among themselves on 97.3-99.2 %
         assert frac >= 0.95, (b, frac, among)

@@ -85,7 +85,7 @@ def test_libm_backed_reference_build_meets_the_metric(oracle_mod):
     """The oracle's exp / exp2 / pow are deterministic stand-ins (oracle/cl_scalar.h).  A build of
     the reference kernel that takes them from the host libm instead -- what a CPU OpenCL runtime
     would most likely do -- agrees with the oracle on BASELINE.json's metric (1e-4 relative) for
-    every pixel, and bit for bit on almost all (tools/pin_report.py: profiles/r02_pin_report.txt)."""
+    every pixel, and bit for bit on almost all (tools/pin_report.py: profiles/archive_r02.txt (FILE r02_pin_report.txt))."""
     if not oracle_mod.have_ref("libm"):
         pytest.skip("libm build missing")
     for name in ("c1_orange", "metal_3spp", "blobs_metal"):

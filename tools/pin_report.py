@@ -15,7 +15,7 @@ relative, maximum and percentiles of the relative difference -- over all pixels 
 pixels that are STABLE under legal re-rounding (|A - C| <= 1e-4 relative: the others flip a
 hit/miss decision somewhere and no two conforming OpenCL builds agree on them).
 
-Build container only (needs /root/reference through oracle/_ref).  Output: profiles/r02_pin_report.txt
+Build container only (needs /root/reference through oracle/_ref).  Output: profiles/archive_r02.txt (FILE r02_pin_report.txt)
 """
 import os
 import sys
