@@ -29,7 +29,7 @@ j = json.load(open(p))
 j["source_digest"] = bench.source_digest()
 json.dump(j, open(p, "w"), indent=1)
 # the bench line below reads it from profiles/
-json.dump(j, open(os.path.join(R, "profiles", "r05_pmc_traffic.json"), "w"), indent=1)
+json.dump(j, open(os.path.join(R, "profiles", "r06_pmc_traffic.json"), "w"), indent=1)
 PY
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 for w in c1 c3 c4 c5; do python bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1; done > $OUT/other_workloads.txt

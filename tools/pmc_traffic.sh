@@ -2,7 +2,7 @@
 # HBM-side traffic of the frame kernel for the CURRENT build: rocprofv3 --pmc FETCH_SIZE and
 # WRITE_SIZE in separate passes (counters only), summarised into gpurun_out/pmc_traffic.json
 # together with the digest of the sources (bench.py reports roofline.traffic only for a
-# matching digest).  Copy the JSON to profiles/r04_pmc_traffic.json.
+# matching digest).  Copy the JSON to profiles/r06_pmc_traffic.json.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
