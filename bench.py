@@ -216,9 +216,16 @@ def main():
                          "(checked against the CPU oracle).  Rounds <= 4 benchmarked the strict contract by default: "
                          "compare round-over-round numbers per contract (`other_contract` carries the others)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true",
+                    help="the timed frames and the roofline only: no host-boundary / animated-volume / other-contract / "
+                         "reference-kernel legs, no CPU baseline (profiling runs: rocprofv3 then sees the frame kernel "
+                         "of the timed region and nothing that runs beside it)")
     ap.add_argument("--cpu-passes", type=int, default=4, help="passes of the workload the CPU baseline renders")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r06_pmc_traffic.json"))
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = True
+        args.frames_in_flight = 1
     if args.contract == "gfx950":  # the name rounds 2-4 used
         args.contract = "gfx950-strict"
 
@@ -429,7 +436,7 @@ def main():
         if per_rank:
             out["per_rank"] = per_rank
             out["argb_exchange"] = argb_exchange
-        if world == 1:
+        if world == 1 and not args.lean:
             # the same frame through the host-buffer boundary (rm_render_frame: tables +
             # records up, float4 accumulator + ARGB back over PCIe) -- never `value`
             hctx = _native.Context(local_rank)
@@ -486,7 +493,7 @@ def main():
                                             "only the 3.7 MB ARGB image comes back, which is all the reference's pipeline reads "
                                             "(core.clj:91-97): what a JNI caller of the reference's render loop gets; _pinned: the "
                                             "caller's buffers registered with rm_pin_host_buffer"}
-        if world == 1:
+        if world == 1 and not args.lean:
             # the other arithmetic contracts, same frame, strictly serial (reported, never `value`)
             out["other_contract"] = []
             for other in ("gfx950-default", "gfx950-strict", "cpu"):

@@ -345,13 +345,6 @@ int rm_debug_get_accel(rm_ctx* ctx, int iso, uint8_t* dist_out, uint32_t* surf_o
  * the largest cube of empty in-grid cells with that cell as its corner, extending in
  * the walking direction (0 = hit cell, capped at 255). */
 int rm_debug_get_octants(rm_ctx* ctx, int iso, uint8_t* oct_out);
-/* The 8 slab tables (csrc/rm_accel.hip slab8; built behind the directional ones for cubic 256^3 / 512^3 / 1024^3 volumes
- * whose voids are flat along z -- a gate at table-build time decides, RAYMARCH_SLABS=0/1 overrides): slab_out = 8 * rx*ry*rz
- * bytes (NULL: only the answer), table o per cell  hit ? 0 : N + 1,  N = the largest n such that the box of
- * K n x K n x n cells (K = 4) with that cell as its corner, extending in walking direction o, is empty and in the grid.
- * *gate_ratio (nullable) = the gate's figure: mean lateral reach of the boxes / mean cube edge over the empty cells of
- * octant 0 (>= 1.5 builds them; 0 when the gate did not run).  RM_ESTATE when the tables are not built. */
-int rm_debug_get_slabs(rm_ctx* ctx, int iso, uint8_t* slab_out, double* gate_ratio);
 /* The part of the image height (fractions, 0 = top row; *lo = *hi = 0: none) whose tile rows the frame kernel
  * dispatches FIRST: the rows in which the clip box [voxelBoundsMin, voxelBoundsMax] of the 544-byte record `opts`
  * covers at least half as much of the image's width as in the row where it covers most -- the box's edges through the

@@ -68,7 +68,7 @@ EXPORTS = [
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_frame_device_argb", "rm_resolve_device_argb", "rm_last_frame_breakdown",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_debug_get_slabs", "rm_debug_volume_band", "rm_selftest_prims", "rm_selftest_filter",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_debug_volume_band", "rm_selftest_prims", "rm_selftest_filter",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
@@ -242,7 +242,6 @@ def lib():
     L.rm_selftest_filter.argtypes = [_vp, _vp, _vp, _i, _vp]
     L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
     L.rm_debug_get_octants.argtypes = [_vp, _i, _vp]
-    L.rm_debug_get_slabs.argtypes = [_vp, _i, _vp, ctypes.POINTER(ctypes.c_double)]
     L.rm_debug_volume_band.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
@@ -563,17 +562,6 @@ class Context:
         out = np.zeros(8 * rx * ry * rz, dtype=np.uint8)
         check(lib().rm_debug_get_octants(self._h, iso, out.ctypes.data))
         return out.reshape(8, rz, ry, rx)
-
-    def debug_get_slabs(self, iso, want_tables=True):
-        """-> (uint8 [8, rz, ry, rx] or None, gate ratio): the slab tables of the resident volume; None when not built."""
-        rx, ry, rz = self.vres
-        ratio = ctypes.c_double()
-        out = np.zeros(8 * rx * ry * rz, dtype=np.uint8) if want_tables else None
-        rc = lib().rm_debug_get_slabs(self._h, iso, out.ctypes.data if want_tables else None, ctypes.byref(ratio))
-        if rc != 0:
-            lib().rm_last_error()
-            return None, float(ratio.value)
-        return (out.reshape(8, rz, ry, rx) if want_tables else None), float(ratio.value)
 
     def selftest_filter(self, opts, rays):
         """rays: float32 [n, 8] (origin, direction, t, g) -> uint32 [n] of decision bits (header)."""

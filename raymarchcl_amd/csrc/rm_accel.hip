@@ -276,107 +276,6 @@ __global__ __launch_bounds__(256) void oct_tile_kernel(const uint8_t* __restrict
   }
 }
 
-// ---- slab8: directional empty-BOX sizes (round 6) -------------------------------------------
-// A cube ahead of a cell is capped by the THINNEST free dimension: in a volume whose voids are flat -- the reference's
-// gyroid generator fills only the slabs (z & 63) >= 32 (generators.clj), so every void is 32 cells thick and as wide as
-// the grid -- a walk that runs along such a slab fetches a table byte every 2-3 samples although hundreds of cells ahead
-// of it are empty.  slab8[o][q] certifies boxes of aspect (K, K, 1): N = the largest n such that the box of
-// K n x K n x n cells with q as its corner, extending AHEAD of the walk (sign octant o), is empty and inside the grid;
-// stored as  hit(q) ? 0 : N + 1  (capped at 255), so that 0 marks exactly the hit cells, like every other table, and
-// a cell whose own K x K x 1 block is not free holds 1.  A walk within the aspect's cone (K |dz| <= max(|dx|, |dy|))
-// reads this table with the SAME per-trip code and other per-walk constants (rm_shade.hpp scene_distance).
-// Dynamic programme: the box of n blocks at q is covered by q's own K x K x 1 block and the seven boxes of n - 1 blocks
-// at q + s*(K i, K j, l), (i, j, l) in {0,1}^3 \ 0, so  N(q) = block_free(q) ? 1 + min over those seven of N : 0.  Same
-// tile diagonals and plane sweep as oct_tile_kernel (every dependency lies in an earlier plane la + lb + lc); the halo
-// ahead of a tile is K cells deep along x and y.
-constexpr int kSlabK = RM_SLAB_ASPECT;
-constexpr int kSlabW = kOctTile + kSlabK;               // la, lb in [-K, 15]
-constexpr int kSlabPlane = kSlabW * kSlabW;             // bytes per plane (lb, la)
-constexpr int kSlabPlanes = 2 * kSlabW + kOctLds - 2;   // t + 2K + 1 for la, lb in [-K, 15], lc in [-1, 15]
-__device__ __forceinline__ int slab_lds_index(int la, int lb, int lc) {
-  return (la + lb + lc + 2 * kSlabK + 1) * kSlabPlane + (lb + kSlabK) * kSlabW + (la + kSlabK);
-}
-__global__ __launch_bounds__(256) void slab_tile_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
-                                                        uint8_t* __restrict__ out8, int k, int a_lo, int nb, int nc,
-                                                        long long table_bytes, int bricked, int o_first) {
-  __shared__ uint8_t s[kSlabPlanes * kSlabPlane];             // plane-major, as in oct_tile_kernel
-  __shared__ uint8_t blockfree[kOctTile * kOctTile * kOctTile];  // the cell's own K x K x 1 block is empty and in the grid
-  const int o = o_first + (int)blockIdx.y;  // (the gate builds octant 0 alone, the other seven afterwards)
-  const bool nx = o & 1, ny = o & 2, nz = o & 4;
-  const int A = a_lo + (int)(blockIdx.x / nb), B = (int)(blockIdx.x % nb), C = k - A - B;
-  if (C < 0 || C >= nc) return;
-  const long long sy = d.rx, sz = (long long)d.rx * d.ry;
-  uint8_t* __restrict__ tab = out8 + (long long)o * table_bytes;
-  const int a0 = A * kOctTile, b0 = B * kOctTile, c0 = C * kOctTile;
-  // fill: tile cells 255 (empty, size unknown) / 0 (hit, or behind the far face); the halo ahead = finished values
-  // (non-zero exactly where the cell is empty), 0 beyond the grid
-  for (int i = threadIdx.x; i < kSlabW * kSlabW * kOctLds; i += 256) {
-    const int la = i % kSlabW - kSlabK, lb = (i / kSlabW) % kSlabW - kSlabK, lc = i / (kSlabW * kSlabW) - 1;
-    const int a = a0 + la, b = b0 + lb, c = c0 + lc;
-    const bool in_tile = la >= 0 && lb >= 0 && lc >= 0;
-    const bool ok = a >= 0 && b >= 0 && c >= 0 && a < d.rx && b < d.ry && c < d.rz;
-    const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
-    uint8_t v = 0;
-    if (ok) v = in_tile ? (vox[(long long)z * sz + (long long)y * sy + x] <= iso ? 255 : 0) : tab[tab_index(d, x, y, z, bricked)];
-    s[slab_lds_index(la, lb, lc)] = v;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kOctTile * kOctTile * kOctTile; i += 256) {
-    const int la = i & (kOctTile - 1), lb = (i >> 4) & (kOctTile - 1), lc = i >> 8;
-    bool fr = true;
-#pragma unroll
-    for (int jb = 0; jb < kSlabK; jb++)
-#pragma unroll
-      for (int ja = 0; ja < kSlabK; ja++) fr &= s[slab_lds_index(la - ja, lb - jb, lc)] != 0;
-    blockfree[i] = fr ? 1 : 0;
-  }
-  __syncthreads();
-  const int la = threadIdx.x & (kOctTile - 1), lb = threadIdx.x >> 4;
-  for (int t = 0; t < 3 * kOctTile - 2; t++) {
-    const int lc = t - la - lb;
-    if (lc >= 0 && lc < kOctTile) {
-      const int i = slab_lds_index(la, lb, lc);
-      if (s[i]) {
-        int v = 1;  // empty, own block not free: N = 0
-        if (blockfree[(lc * kOctTile + lb) * kOctTile + la]) {
-          int m = 255;
-#pragma unroll
-          for (int q = 1; q < 8; q++) {
-            const int nv = s[slab_lds_index(la - ((q & 1) ? kSlabK : 0), lb - ((q & 2) ? kSlabK : 0), lc - ((q & 4) ? 1 : 0))];
-            m = min(m, max(nv - 1, 0));  // the neighbour's N
-          }
-          v = min(255, m + 2);  // N + 1 with N = 1 + min
-        }
-        s[i] = (uint8_t)v;
-      }
-    }
-    __syncthreads();
-  }
-  for (int i = threadIdx.x; i < kOctTile * kOctTile * kOctTile; i += 256) {
-    const int la2 = i & (kOctTile - 1), lb2 = (i >> 4) & (kOctTile - 1), lc2 = i >> 8;
-    const int a = a0 + la2, b = b0 + lb2, c = c0 + lc2;
-    if (a < d.rx && b < d.ry && c < d.rz) {
-      const int x = nx ? a : d.rx - 1 - a, y = ny ? b : d.ry - 1 - b, z = nz ? c : d.rz - 1 - c;
-      tab[tab_index(d, x, y, z, bricked)] = s[slab_lds_index(la2, lb2, lc2)];
-    }
-  }
-}
-
-// gate of the slab tables: over the empty cells of ONE octant, how far do the boxes reach along x / y compared with
-// the cubes?  sums[0] += K * N (box), sums[1] += cube edge, sums[2] += 1
-__global__ __launch_bounds__(256) void slab_gate_kernel(const uint8_t* __restrict__ cube, const uint8_t* __restrict__ box,
-                                                        long long total, unsigned long long* __restrict__ sums) {
-  unsigned long long sb = 0, sc = 0, n = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cv = cube[i], bv = box[i];
-    if (cv) { sb += (unsigned long long)(kSlabK * max(bv - 1, 0)); sc += (unsigned long long)cv; n++; }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    sb += __shfl_down(sb, off, 64); sc += __shfl_down(sc, off, 64); n += __shfl_down(n, off, 64);
-  }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(sums, sb); atomicAdd(sums + 1, sc); atomicAdd(sums + 2, n); }
-}
-
 // dist8 from the eight directional tables: the nearest obstacle lies in one of the closed
 // octants around the cell, so the Chebyshev distance is the smallest of the eight cube edges
 __global__ __launch_bounds__(256) void dist_from_oct_kernel(const uint8_t* __restrict__ oct8, long long total,
@@ -468,29 +367,6 @@ hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, i
   }
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
   dist_from_oct_kernel<<<blocks, 256, 0, st>>>(oct, total, d_dist9);
-  return hipGetLastError();
-}
-
-// the eight slab tables (d_slab8: 8 x table bytes); octants [o_lo, o_hi) only (the gate builds one first)
-hipError_t build_slabs(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso, uint8_t* d_slab8,
-                       bool bricked, int o_lo, int o_hi) {
-  const Dim d{rx, ry, rz};
-  const long long total = bricked ? bricked_bytes(rx, ry, rz) : (long long)rx * ry * rz;
-  const int na = (rx + kOctTile - 1) / kOctTile, nb = (ry + kOctTile - 1) / kOctTile,
-            nc = (rz + kOctTile - 1) / kOctTile;
-  for (int k = 0; k < na + nb + nc - 2; k++) {
-    const int a_lo = max(0, k - (nb - 1) - (nc - 1)), a_hi = min(na - 1, k);
-    if (a_hi < a_lo) continue;
-    const dim3 grid((unsigned)((a_hi - a_lo + 1) * nb), (unsigned)(o_hi - o_lo));
-    slab_tile_kernel<<<grid, 256, 0, st>>>(d_vox, d, iso, d_slab8, k, a_lo, nb, nc, total, bricked ? 1 : 0, o_lo);
-  }
-  return hipGetLastError();
-}
-// sums[0] / sums[1] = mean lateral reach of the boxes / mean cube edge over the empty cells of octant 0
-hipError_t launch_slab_gate(hipStream_t st, const uint8_t* d_cube0, const uint8_t* d_slab0, long long table_bytes,
-                            unsigned long long* d_sums) {
-  const int blocks = (int)((table_bytes + 255) / 256 > 4096 ? 4096 : (table_bytes + 255) / 256);
-  slab_gate_kernel<<<blocks, 256, 0, st>>>(d_cube0, d_slab0, table_bytes, d_sums);
   return hipGetLastError();
 }
 

@@ -76,8 +76,6 @@ struct Volume {
   int accel_iso = -1;              // isoVal the tables were built for, -1 = stale
   unsigned long long oct_stride = 0;
   bool bricked = false;            // dist8 / oct8 stored in 8x4x4-cell bricks (volumes beyond the caches)
-  bool slabs = false;              // 8 slab tables (boxes of aspect (K, K, 1), rm_accel.hip slab8) follow the directional ones
-  double slab_ratio = 0.0;         // the gate's figure: mean lateral reach of the boxes / mean cube edge, octant 0
   unsigned long long generation = 0;  // bumped whenever the bytes (may) have changed
   double accel_build_ms = 0.0;     // wall time of the last table build (reported by bench.py)
   ~Volume() {
@@ -120,9 +118,6 @@ struct rm_ctx {
   bool use_accel = true;     // RAYMARCH_NO_ACCEL=1 -> plain fixed-step march (A/B)
   int bricks = -1;           // RAYMARCH_BRICKS=0/1: never / always store the tables in bricks (default: by size)
   bool pow2_tables = true;   // RAYMARCH_POW2=0: generic table indexing also for cubic power-of-two grids (A/B)
-  int slab_mode = -1;        // RAYMARCH_SLABS=0/1: never / always build the slab tables; default: by the gate (enqueue_slabs)
-  int slab_last = 0;         // the last gate decision of this context (what a STAGED volume gets: no host wait there)
-  DevBuf gate_buf;           // the gate's three sums
   int seed_cast = 0;         // rm_set_seed_cast: RM_SEED_CAST_X86 (default) / RM_SEED_CAST_GPU
   int contract = RM_CONTRACT_GFX950_DEFAULT;  // (library default, ABI 4) rm_set_contract: RM_CONTRACT_GFX950_STRICT / RM_CONTRACT_GFX950_DEFAULT / RM_CONTRACT_CPU_DEVICE
   // records validated by rm_check_device_opts
@@ -211,15 +206,7 @@ static bool tables_possible(const rm_ctx* c, const Volume& v) {
 // Enqueue the build of dist8 / oct8 / surf32 of `v` for hit threshold `iso` on stream `st`, bracketed by the timed events
 // t0 / t1.  No host synchronisation: the caller decides who may see the tables when (ensure_accel waits; a staged
 // volume -- rm_stage_volume_device -- hands an event to the stream that will render it).
-// slab tables exist only for the grids whose frame kernels have the edge compiled in (walk_step layouts 5, 3, 4: cubic
-// 256^3 row-major, 512^3 and 1024^3 in bricks) -- BASELINE's --, with directional tables
-static bool slabs_possible(const rm_ctx* c, const Volume& v, bool bricked) {
-  if (!c->use_octants || !c->pow2_tables || c->slab_mode == 0) return false;
-  if (v.rx != v.ry || v.ry != v.rz) return false;
-  return (v.rx == 256 && !bricked) || ((v.rx == 512 || v.rx == 1024) && bricked);
-}
-
-static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEvent_t t0, hipEvent_t t1, bool sync_gate) {
+static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
   const size_t vox = (size_t)v.rx * v.ry * v.rz;
   // directional tables behind dist8 (measured -10 % frame time at 256^3, -12 % at 512^3 with
   // 8 % fill); table offsets are 64-bit, nine 1024^3 tables span 9 GiB
@@ -233,7 +220,7 @@ static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEven
   const bool bricked = oct &&
                        (c->bricks >= 0 ? c->bricks == 1 : (vox * 13 > ((size_t)4 << 30) || cube512));
   const size_t tbytes = bricked ? (size_t)rmk::bricked_bytes(v.rx, v.ry, v.rz) : vox;
-  HIP_TRY(v.dist_buf.reserve(tbytes * (tables + (slabs_possible(c, v, bricked) ? 8 : 0))));
+  HIP_TRY(v.dist_buf.reserve(tbytes * tables));
   uint8_t* lin = static_cast<uint8_t*>(v.dist_buf.p);
   HIP_TRY(v.surf_buf.reserve(vox * 4));
   HIP_TRY(hipEventRecord(t0, st));
@@ -250,34 +237,6 @@ static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEven
     HIP_TRY(rmk::build_accel(st, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
                              static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
   }
-  // SLAB TABLES behind the directional ones, for volumes whose voids are flat along z (rm_accel.hip slab8).  The gate:
-  // octant 0's table is built first (1/8 of the work) and compared with the cubes over the empty cells -- mean lateral
-  // reach K N of the boxes against the mean cube edge; below 1.5 the other seven are not built and the kernels never
-  // look (a volume without slab-like voids pays one octant: +~10 % of the table build).  `sync_gate`: the caller can
-  // wait for the sums (ensure_accel); a staged build cannot and takes the context's last decision.
-  v.slabs = false;
-  v.slab_ratio = 0.0;
-  if (slabs_possible(c, v, bricked)) {
-    uint8_t* slab8 = lin + tbytes * 9;
-    int decided = c->slab_mode;
-    if (decided < 0 && !sync_gate) decided = c->slab_last;
-    if (decided < 0) {
-      HIP_TRY(c->gate_buf.reserve(3 * sizeof(unsigned long long)));
-      HIP_TRY(hipMemsetAsync(c->gate_buf.p, 0, 3 * sizeof(unsigned long long), st));
-      HIP_TRY(rmk::build_slabs(st, v.d_vox, v.rx, v.ry, v.rz, iso, slab8, bricked, 0, 1));
-      HIP_TRY(rmk::launch_slab_gate(st, lin + tbytes, slab8, (long long)tbytes, static_cast<unsigned long long*>(c->gate_buf.p)));
-      unsigned long long sums[3] = {0, 0, 0};
-      HIP_TRY(hipMemcpyAsync(sums, c->gate_buf.p, sizeof sums, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      v.slab_ratio = sums[1] ? (double)sums[0] / (double)sums[1] : 0.0;
-      decided = v.slab_ratio >= 1.5 ? 1 : 0;
-      c->slab_last = decided;
-      if (decided) HIP_TRY(rmk::build_slabs(st, v.d_vox, v.rx, v.ry, v.rz, iso, slab8, bricked, 1, 8));
-    } else if (decided > 0) {
-      HIP_TRY(rmk::build_slabs(st, v.d_vox, v.rx, v.ry, v.rz, iso, slab8, bricked, 0, 8));
-    }
-    v.slabs = decided > 0;
-  }
   HIP_TRY(hipEventRecord(t1, st));
   return RM_OK;
 }
@@ -290,7 +249,7 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   const size_t vox = (size_t)v.rx * v.ry * v.rz;
   std::lock_guard<std::mutex> lock(v.mu);
   if (v.accel_iso != iso) {
-    int rc = enqueue_tables(c, v, iso, c->stream, c->ev_b0, c->ev_b1, true);
+    int rc = enqueue_tables(c, v, iso, c->stream, c->ev_b0, c->ev_b1);
     if (rc) return rc;
     // contexts that share the volume run on other streams: the tables are complete before
     // anybody else can see accel_iso
@@ -302,7 +261,6 @@ int ensure_accel(rm_ctx* c, int iso, rmk::Accel* out) {
   }
   out->oct_stride = v.oct_stride;
   out->bricked = v.bricked;
-  out->slabs = v.slabs;
   // cubic power-of-two grid whose tables stay below 4 GiB: shift-or cell index, 32-bit buffer offsets
   // (bricked tables: only on the 512^3 grid with octants, walk_step LAYOUT 3 has that edge compiled in)
   if ((!v.bricked || ((v.rx == 512 || v.rx == 1024) && v.oct_stride)) && v.rx == v.ry && v.ry == v.rz && (v.rx & (v.rx - 1)) == 0 && v.rx >= 2 &&
@@ -647,7 +605,6 @@ static int create_one(int device_id, rm_ctx** out) {
   if (xr) c->xcd_rows = xr[0] != '0';
   const char* ro = getenv("RAYMARCH_ROW_ORDER");
   if (ro) c->rows_desc = !(ro[0] == 'a');
-  if (const char* sl = getenv("RAYMARCH_SLABS")) c->slab_mode = sl[0] == '0' ? 0 : (sl[0] == '1' ? 1 : -1);
   if (ro) c->rows_band = ro[0] == 'b';  // "desc" (default) / "band" / "asc"
   if (const char* rb = getenv("RAYMARCH_ROW_BAND")) (void)sscanf(rb, "%lf,%lf", &c->band_fixed_lo, &c->band_fixed_hi);
   const char* pk = getenv("RAYMARCH_PASS_PACK");
@@ -715,7 +672,6 @@ void rm_destroy(rm_ctx* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (const void* h : c->host_bufs) (void)hipHostUnregister(const_cast<void*>(h));
   c->host_bufs.clear();
-  c->gate_buf.release();
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
                     &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->sdfq_buf, &c->atile_buf};
   for (DevBuf* b : bufs) b->release();
@@ -904,7 +860,7 @@ int rm_stage_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int 
   if (c->back_free_pending) HIP_TRY(hipStreamWaitEvent(c->prep_stream, c->ev_back_free, 0));
   c->back_free_pending = false;
   if (tables_possible(c, v)) {
-    rc = enqueue_tables(c, v, iso_val, c->prep_stream, c->ev_s0, c->ev_s1, false);
+    rc = enqueue_tables(c, v, iso_val, c->prep_stream, c->ev_s0, c->ev_s1);
     if (rc) { v.d_vox = nullptr; return rc; }
     v.accel_iso = iso_val;  // (visible to the context's stream behind ev_staged only: rm_commit_staged_volume)
     c->staged_timing = true;
@@ -1534,33 +1490,6 @@ int rm_debug_get_accel(rm_ctx* c, int iso, uint8_t* dist_out, uint32_t* surf_out
   } else if (dist_out)
     HIP_TRY(hipMemcpyAsync(dist_out, accel.dist, vox, hipMemcpyDeviceToHost, c->stream));
   if (surf_out) HIP_TRY(hipMemcpyAsync(surf_out, accel.surf, vox * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return RM_OK;
-}
-
-int rm_debug_get_slabs(rm_ctx* c, int iso, uint8_t* slab_out, double* gate_ratio) {
-  int rc = check_ctx(c);
-  if (rc) return rc;
-  if (!have_volume(c)) return fail(RM_ESTATE, "rm_set_volume has not been called");
-  if (iso < 0 || iso > 255) return fail(RM_EINVAL, "bad argument");
-  rmk::Accel accel;
-  rc = ensure_accel(c, iso, &accel);
-  if (rc) return rc;
-  if (gate_ratio) *gate_ratio = c->vol->slab_ratio;
-  if (!accel.slabs) return fail(RM_ESTATE, "slab tables are not built (the gate said no, RAYMARCH_SLABS=0, or not a cubic 256/512/1024 grid)");
-  if (!slab_out) return RM_OK;
-  const size_t vox = (size_t)c->vol->rx * c->vol->ry * c->vol->rz;
-  if (accel.bricked) {
-    HIP_TRY(c->vol->tmp_buf.reserve(vox));
-    for (int t = 0; t < 8; t++) {
-      HIP_TRY(rmk::launch_unbrick(c->stream, accel.dist + (size_t)(t + 9) * accel.oct_stride, c->vol->rx,
-                                  c->vol->ry, c->vol->rz, static_cast<uint8_t*>(c->vol->tmp_buf.p)));
-      HIP_TRY(hipMemcpyAsync(slab_out + (size_t)t * vox, c->vol->tmp_buf.p, vox, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-  } else {
-    HIP_TRY(hipMemcpyAsync(slab_out, accel.dist + vox * 9, vox * 8, hipMemcpyDeviceToHost, c->stream));
-  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RM_OK;
 }

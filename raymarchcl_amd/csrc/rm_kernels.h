@@ -18,7 +18,6 @@ struct Accel {  // nullptrs = not available: the kernels then run the plain fixe
   // > 0: `dist` is followed by 8 directional tables (rm_accel.hip oct8), each this many bytes
   unsigned long long oct_stride = 0;
   bool bricked = false;             // dist / oct tables in 8x4x4-cell bricks of 128 B (oct_stride = bricked table bytes)
-  bool slabs = false;               // the 8 directional tables are followed by 8 slab tables (rm_accel.hip slab8: boxes of aspect (K, K, 1))
   unsigned log2res = 0;             // > 0: cubic grid of edge 1 << log2res, tables below 4 GiB: row-major (walk_step LAYOUT 2) or the bricks of the 512^3 grid (LAYOUT 3); 10 with bricks: the 1024^3 grid (LAYOUT 4)
 };
 // bytes of one byte table in the bricked layout
@@ -75,11 +74,6 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
 // them (table 0); no scratch
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
                          uint8_t* d_dist9, bool bricked = false);
-// the eight slab tables behind the directional ones (d_slab8 = 8 x table bytes), octants [o_lo, o_hi); and the gate's sums
-hipError_t build_slabs(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso, uint8_t* d_slab8,
-                       bool bricked, int o_lo = 0, int o_hi = 8);
-hipError_t launch_slab_gate(hipStream_t st, const uint8_t* d_cube0, const uint8_t* d_slab0, long long table_bytes,
-                            unsigned long long* d_sums);
 hipError_t launch_gyroid(hipStream_t st, uint8_t* d_out, int rx, int ry, int rz);
 // quality mode: float field -> one float4 per cell (the cell's xy-face at its layer), rm_accel.hip
 hipError_t launch_sdf_quads(hipStream_t st, const float* d_field, int rx, int ry, int rz, float* d_quads);

@@ -128,7 +128,6 @@ struct FrameArgs {
   uint32_t* __restrict__ argb;         // row-major ARGB, or nullptr
   int n, resx, tile_first, tile_stride, tiles_per_part, pp_log2, passes, bpr;
   unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
-  int slabs;                           // slab tables behind the directional ones (rm_accel.hip slab8)
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int rows_desc;                       // XCD-aware order: tile rows dispatched bottom to top
   int band_r0, band_r1;                // ... and, when band_r1 > band_r0, the tile rows [band_r0, band_r1) FIRST: the rows whose
@@ -218,8 +217,6 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     const RmOpts* __restrict__ opts = a.opts_all + c0;  // uniform (pp > 1: all of the group equal but .time)
     rmk::Scene sc{a.vox, a.mc_all + (size_t)c0 * RM_TABLE_ENTRIES, opts, a.dist8, a.surf32, a.oct_stride, a.sdf};
     sc.log2res = a.log2res;
-    sc.slabs = a.slabs != 0;
-    sc.slab_k = a.slabs != 0 ? (float)RM_SLAB_ASPECT : __builtin_inff();
     Tr tr(sc);
     if (pp > 1 && live) tr.set_pass(a.mc_all + (size_t)pass * RM_TABLE_ENTRIES, a.opts_all[pass].time);
     rmk::v3 col = rmk::V(0.f, 0.f, 0.f);
@@ -534,7 +531,6 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
 #define RM_SDF_MINW 5  // (quality mode: 4 / 5 / 6 waves per SIMD measured 9.21 / 9.06 / 9.09 ms)
 #endif
   a.log2res = f.accel.log2res;
-  a.slabs = f.accel.slabs ? 1 : 0;
   const bool acc = f.accel.dist && f.accel.surf;
   if (f.sdf) {  // (quality mode: its own algorithm, CPU-device arithmetic only)
     if (f.arith == 1) render_frame_kernel<false, RM_SDF_MINW, true, 0, 1><<<grid, block, 0, st>>>(a);

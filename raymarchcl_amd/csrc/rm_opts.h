@@ -64,8 +64,6 @@ struct alignas(16) RmOpts {
 // AO probes (aoIter + 1) whose results a wavefront's exchange area holds per lane (rm_shade.hpp occlusion_wave): frames whose
 // records ask for more go through the single-pass kernels (rm_api.hip frame_on_device), one launch per pass
 #define RM_WAVE_AO_PROBES 8
-// aspect K of the slab tables (rm_accel.hip slab8): boxes of K n x K n x n cells ahead of a cell, for walks with K |dz| <= max(|dx|, |dy|)
-#define RM_SLAB_ASPECT 4
 #define RM_OPTS_SIZE 544
 #define RM_TABLE_ENTRIES 0x4000
 static_assert(sizeof(RmMaterial) == 32, "TMaterial is 32 bytes");

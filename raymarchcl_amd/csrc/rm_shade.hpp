@@ -33,9 +33,6 @@ struct Scene {
   unsigned long long oct_stride = 0;  // > 0: 8 directional tables follow dist8 (rm_accel.hip oct8)
   const float* __restrict__ sdf = nullptr;  // quality mode: the distance field, one float4 xy-face per cell (Tracer<.., SDFM = true>)
   unsigned log2res = 0;   // LAYOUT 2 (walk_step): edge of the cubic grid = 1 << log2res
-  // tables 9..16 = slab8 (rm_accel.hip): boxes of aspect (K, K, 1) ahead of a cell, per sign octant; slab_k = K with them, +inf without
-  bool slabs = false;
-  float slab_k = __builtin_inff();
 };
 
 // ---- leaf routines; `o` points at the option record in device memory ----
@@ -160,11 +157,6 @@ constexpr bool bricks_by_shifts(int layout) { return layout == 3 || layout == 4;
 constexpr unsigned fixed_log2(int layout) {
   return layout == 3 ? kLog2Res3 : (layout == 4 ? kLog2Res4 : (layout == 5 ? kLog2Res5 : 0u));
 }
-// table layouts whose kernels look at the slab tables (rm_accel.hip slab8): bit LAYOUT of RM_SLAB_LAYOUTS
-#ifndef RM_SLAB_LAYOUTS
-#define RM_SLAB_LAYOUTS ((1 << 3) | (1 << 4) | (1 << 5))
-#endif
-constexpr bool slab_layout(int layout) { return fixed_log2(layout) != 0 && ((RM_SLAB_LAYOUTS >> layout) & 1) != 0; }
 struct WalkTab {
   const uint8_t* __restrict__ dist8;   // table 0; tables 1..8 follow at oct_stride
   __amdgpu_buffer_rsrc_t rsrc;         // LAYOUT 2, 3, 5: all nine tables as one buffer
@@ -290,7 +282,7 @@ struct Tracer {
     tab_.res = 1u << s.log2res;
     tab_.fres = (float)(1u << s.log2res);
     if (LAYOUT == 2 || LAYOUT == 3 || LAYOUT == 5) {
-      const unsigned long long bytes = (s.oct_stride ? (s.slabs ? 17ull : 9ull) : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
+      const unsigned long long bytes = (s.oct_stride ? 9ull : 1ull) << (3u * s.log2res);  // < 4 GiB (host)
       tab_.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s.dist), 0, (int)(unsigned)bytes, 0x00020000);
     }
   }
@@ -529,30 +521,14 @@ struct Tracer {
         const float s = LAYOUT >= 2 ? fmaxf(fmaxf(__builtin_fabsf(delta.x), __builtin_fabsf(delta.y)), __builtin_fabsf(delta.z))
                                     : fmaxf(fmaxf(__builtin_fabsf(delta.x) * frx, __builtin_fabsf(delta.y) * fry),
                                             __builtin_fabsf(delta.z) * frz);
+        const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(s, 1e-6f));
+        const float c0 = 1.0f - inv_s;
         // directional table of this walk (a walk never moves against the signs of delta)
-        unsigned int tno = 1u + ((delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u));
-        // SLAB TABLES (round 6; layouts with the grid edge compiled in): a walk inside the cone of the tables' aspect --
-        // K |dz| <= max(|dx|, |dy|) -- reads boxes of K n x K n x n cells ahead instead of cubes.  A table value d = N + 1
-        // (N = n of the largest such box; 0 = hit, 1 = not even the cell's own K x K x 1 block is free) certifies that the
-        // next j - 1 samples lie in empty in-grid cells for  j = 1 + floor(0.98 (N - 1) K / max(|dx|, |dy|)):  sample m is
-        // at most m |d_a| cells from sample 0 along axis a, so its cell differs from the corner's by <= floor(m |d_a|) + 1;
-        // with m <= 0.98 K (N - 1) / max(|dx|, |dy|) that stays below K N along x and y, and -- the cone -- floor(m |dz|)
-        // <= N - 2 along z.  Same one-fma form as the cubes' rule with other per-walk constants: inv_s' = 0.98 K /
-        // max(|dx|, |dy|), c0' = 1 - 2 inv_s' (d - 2 = N - 1); max(., 1) catches d = 1.  Exact by construction: only the
-        // number of fetches changes.  (tests/test_gpu_skip_invariant.py replays the rule on the host.)  Straight-line:
-        // sc.slab_k = K with the tables, +inf without (inf |dz| <= sxy is false, also for dz = 0: NaN).
-        bool slab = false;
-        float se = s;
-        if (slab_layout(LAYOUT)) {
-          const float sxy = fmaxf(__builtin_fabsf(delta.x), __builtin_fabsf(delta.y));
-          slab = sc.slab_k * __builtin_fabsf(delta.z) <= sxy;
-          se = slab ? sxy * (1.0f / (float)RM_SLAB_ASPECT) : s;
-          tno += slab ? 8u : 0u;
+        unsigned long long table_off = 0;  // 64-bit: nine 1024^3 tables span 9 GiB
+        if (sc.oct_stride) {
+          const unsigned int oct = (delta.x < 0.0f ? 1u : 0u) | (delta.y < 0.0f ? 2u : 0u) | (delta.z < 0.0f ? 4u : 0u);
+          table_off = LAYOUT == 4 ? (unsigned long long)(oct + 1u) : (oct + 1u) * sc.oct_stride;
         }
-        const float inv_s = 0.98f * __builtin_amdgcn_rcpf(fmaxf(se, 1e-6f));
-        const float c0 = (1.0f - inv_s) - (slab ? inv_s : 0.0f);
-        unsigned long long table_off = 0;  // 64-bit: the tables of a 1024^3 grid span 9 (17) GiB
-        if (sc.oct_stride) table_off = LAYOUT == 4 ? (unsigned long long)tno : tno * sc.oct_stride;
         (void)s;
         // the loop holds nothing but the walk: a lane that finds its hit waits for the
         // others and all hits are then evaluated together (inside the loop the compiler

@@ -10,11 +10,11 @@ OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --frames-in-flight 1 > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --lean > $OUT/kt.log 2>&1
 DB=$(find /tmp/kt -name "*_results.db" | head -1)
 python $R/tools/rocprof_summary.py $DB > $OUT/kernel_stats.txt 2>&1
 cd $R
-tools/pmc_run.sh final/pmc --steps 8 --warmup 2 --frames-in-flight 1 > $OUT/pmc_run.log 2>&1
+tools/pmc_run.sh final/pmc --steps 8 --warmup 2 --lean > $OUT/pmc_run.log 2>&1
 python tools/pmc_summary.py $OUT/pmc/p1/pmc_results.db $OUT/pmc/p2/pmc_results.db $OUT/pmc/p3/pmc_results.db \
   $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 5, 3>" > $OUT/pmc.txt 2>&1
 python tools/pmc_summary.py $OUT/pmc/p4/pmc_results.db $OUT/pmc/p5/pmc_results.db --kernel "render_frame_kernel<true, 7, false, 5, 3>" \
