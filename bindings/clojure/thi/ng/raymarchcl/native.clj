@@ -120,6 +120,25 @@
 
 (defn release [state] (Native/destroy (:handle state)))
 
+(defn render-volume-sequence
+  "A new volume per frame (the reference's heat-map animation, meshvoxel.clj:85-89 feeding core.clj:181-213):
+  `volumes` = a seq of direct ByteBuffers of the resident volume's resolution `[rx ry rz]`; `f` is called with the
+  frame number and the ARGB IntBuffer of each frame (e.g. to write a PNG).  While `f` works on frame k the library
+  builds the tables of volume k+1 on its own stream (stageVolume), so no frame waits for them."
+  [state [rx ry rz] volumes f]
+  (let [handle (:handle state)
+        iso    32]
+    (when-let [v0 (first volumes)]
+      (Native/stageVolume handle v0 rx ry rz iso)
+      (Native/commitStagedVolume handle)
+      (loop [k 0, more (rest volumes)]
+        (let [argb (execute-pipeline state)]
+          (when-let [v (first more)] (Native/stageVolume handle v rx ry rz iso))
+          (f k argb)
+          (when (first more)
+            (Native/commitStagedVolume handle)
+            (recur (inc k) (rest more))))))))
+
 (defn- save-frame!
   [^IntBuffer argb img path]
   (let [dst (pix/get-pixels img)]

@@ -20,6 +20,10 @@ public final class Native {
     public static native int deviceCount();
     public static native void destroy(long handle);
     public static native int setVolume(long handle, ByteBuffer voxels, int rx, int ry, int rz);
+    /** The volume of the NEXT animation frame: copied, its derived tables built on the library's own stream (no wait);
+     *  commitStagedVolume makes it the resident one for every later call. */
+    public static native int stageVolume(long handle, ByteBuffer voxels, int rx, int ry, int rz, int isoVal);
+    public static native int commitStagedVolume(long handle);
     public static native int makeGyroidVolume(long handle, int rx, int ry, int rz, ByteBuffer voxelsOut);
     public static native int renderImage(long handle, ByteBuffer mc, ByteBuffer opts, ByteBuffer pixels, int n);
     public static native int tonemapImage(long handle, ByteBuffer pixels, ByteBuffer opts, ByteBuffer argb, int n);

@@ -89,6 +89,19 @@ JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_setVolume(JNIEnv* env, jcla
   if (!p) return RM_EINVAL;
   return check(env, rm_set_volume(CTX(h), p, rx, ry, rz));
 }
+/* the volume of the NEXT animation frame (meshvoxel.clj:85-89 make-heatmap-anim -> core.clj:181-213): its tables are built
+ * on the library's own stream while the host still works on the current frame; commitStagedVolume makes it resident */
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_stageVolume(JNIEnv* env, jclass c, jlong h, jobject vox, jint rx,
+                                                                jint ry, jint rz, jint isoVal) {
+  (void)c;
+  const uint8_t* p = (const uint8_t*)addr_of(env, vox, (jlong)rx * ry * rz, "voxels: direct ByteBuffer too small");
+  if (!p) return RM_EINVAL;
+  return check(env, rm_stage_volume(CTX(h), p, rx, ry, rz, isoVal));
+}
+JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_commitStagedVolume(JNIEnv* env, jclass c, jlong h) {
+  (void)c;
+  return check(env, rm_commit_staged_volume(CTX(h)));
+}
 /* gen/make-gyroid-volume (generators.clj:27-42) on the device; voxelsOut may be null */
 JNIEXPORT jint JNICALL Java_thi_ng_raymarchcl_Native_makeGyroidVolume(JNIEnv* env, jclass c, jlong h, jint rx,
                                                                      jint ry, jint rz, jobject voxelsOut) {

@@ -55,6 +55,8 @@ jint Java_thi_ng_raymarchcl_Native_deviceCount(JNIEnv*, jclass);
 void Java_thi_ng_raymarchcl_Native_destroy(JNIEnv*, jclass, jlong);
 jint Java_thi_ng_raymarchcl_Native_setVolume(JNIEnv*, jclass, jlong, jobject, jint, jint, jint);
 jint Java_thi_ng_raymarchcl_Native_makeGyroidVolume(JNIEnv*, jclass, jlong, jint, jint, jint, jobject);
+jint Java_thi_ng_raymarchcl_Native_stageVolume(JNIEnv*, jclass, jlong, jobject, jint, jint, jint, jint);
+jint Java_thi_ng_raymarchcl_Native_commitStagedVolume(JNIEnv*, jclass, jlong);
 jint Java_thi_ng_raymarchcl_Native_renderImage(JNIEnv*, jclass, jlong, jobject, jobject, jobject, jint);
 jint Java_thi_ng_raymarchcl_Native_tonemapImage(JNIEnv*, jclass, jlong, jobject, jobject, jobject, jint);
 jint Java_thi_ng_raymarchcl_Native_renderFrame(JNIEnv*, jclass, jlong, jobject, jobject, jint, jint, jobject, jobject);
@@ -91,7 +93,7 @@ int main(int argc, char** argv) {
   uint32_t* argb = calloc(n, 4);
   float* px1 = calloc((size_t)n * 4, 4);
   uint32_t* argb1 = calloc(n, 4);
-  int32_t checks[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t checks[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   if (Java_thi_ng_raymarchcl_Native_deviceCount(env, NULL) < 1) return 4;
   const jlong h = Java_thi_ng_raymarchcl_Native_create(env, NULL, 0);
@@ -210,6 +212,22 @@ int main(int argc, char** argv) {
     checks[6] = checks[6] && ok;
     free(pxp);
   }
+  /* staged volumes through the shim: another volume is resident, the scene's volume is staged + committed, the frame
+   * equals the first one; a commit without a stage raises */
+  {
+    float* pxs = calloc((size_t)n * 4, 4);
+    struct rm_test_jobject_ bps = buf(pxs, (size_t)n * 16);
+    g_throws = 0;
+    checks[9] = Java_thi_ng_raymarchcl_Native_makeGyroidVolume(env, NULL, h, rx, ry, rz, NULL) == 0 &&
+                Java_thi_ng_raymarchcl_Native_stageVolume(env, NULL, h, &bvox, rx, ry, rz, 32) == 0 &&
+                Java_thi_ng_raymarchcl_Native_commitStagedVolume(env, NULL, h) == 0 &&
+                Java_thi_ng_raymarchcl_Native_renderFrame(env, NULL, h, &bopts, &bmc, iter, n, &bps, NULL) == 0 &&
+                memcmp(pxs, px, (size_t)n * 16) == 0 && g_throws == 0;
+    Java_thi_ng_raymarchcl_Native_commitStagedVolume(env, NULL, h);
+    checks[9] = checks[9] && g_throws == 1;
+    g_throws = 0;
+    free(pxs);
+  }
   /* the arithmetic contract through the shim: accepted values, a bad value raises */
   g_throws = 0;
   checks[8] = Java_thi_ng_raymarchcl_Native_setContract(env, NULL, h, 1) == 0 &&
@@ -224,7 +242,7 @@ int main(int argc, char** argv) {
   fwrite(argb, 4, n, f);
   fwrite(px1, 4, (size_t)n * 4, f);
   fwrite(argb1, 4, n, f);
-  fwrite(checks, 4, 9, f);
+  fwrite(checks, 4, 10, f);
   fclose(f);
   return 0;
 }

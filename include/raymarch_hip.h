@@ -165,6 +165,10 @@ int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int 
  * rm_check_device_opts accepted when the new volume has the old one's resolution.  Single-device contexts only;
  * contexts that shared the old volume keep rendering it.  Pixels are those of rm_set_volume_device + the same frame. */
 int rm_stage_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int rz, int iso_val);
+/* The same for volume bytes in HOST memory (what a JNI caller has: a direct ByteBuffer, or the output of
+ * rm_make_heatmap_volume): copied into a buffer the library owns; returns once the bytes have been taken -- the copy,
+ * not the build, is waited for. */
+int rm_stage_volume(rm_ctx* ctx, const uint8_t* voxels, int rx, int ry, int rz, int iso_val);
 int rm_commit_staged_volume(rm_ctx* ctx);
 
 int rm_invalidate_volume(rm_ctx* ctx);

@@ -63,7 +63,7 @@ EXPORTS = [
     "rm_last_error", "rm_abi_version", "rm_device_count", "rm_create", "rm_create_multi", "rm_num_devices",
     "rm_destroy", "rm_set_stream", "rm_set_seed_cast", "rm_set_contract", "rm_synchronize", "rm_pin_host_buffer",
     "rm_unpin_host_buffer", "rm_set_volume", "rm_set_volume_device",
-    "rm_invalidate_volume", "rm_share_volume", "rm_stage_volume_device", "rm_commit_staged_volume", "rm_frame_device_full", "rm_last_table_build_ms",
+    "rm_invalidate_volume", "rm_share_volume", "rm_stage_volume_device", "rm_stage_volume", "rm_commit_staged_volume", "rm_frame_device_full", "rm_last_table_build_ms",
     "rm_make_gyroid_volume", "rm_make_terrain_volume", "rm_voxelize_vertices", "rm_voxelize_scatter", "rm_make_heatmap_volume",
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
@@ -217,6 +217,7 @@ def lib():
     L.rm_set_volume.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_set_volume_device.argtypes = [_vp, _vp, _i, _i, _i]
     L.rm_stage_volume_device.argtypes = [_vp, _vp, _i, _i, _i, _i]
+    L.rm_stage_volume.argtypes = [_vp, _vp, _i, _i, _i, _i]
     L.rm_commit_staged_volume.argtypes = [_vp]
     L.rm_make_gyroid_volume.argtypes = [_vp, _i, _i, _i, _vp]
     L.rm_make_terrain_volume.argtypes = [_vp, _i, _i, _i, _vp]
@@ -322,6 +323,15 @@ class Context:
         one renders; returns at once (rm_stage_volume_device)."""
         rx, ry, rz = (int(v) for v in vres)
         check(lib().rm_stage_volume_device(self._h, dptr, rx, ry, rz, int(iso_val)))
+        self._staged_vres = (rx, ry, rz)
+
+    def stage_volume(self, vox, vres, iso_val=32):
+        """The same from host bytes (uint8 array): copied into a buffer of the library's, returns once they are taken."""
+        rx, ry, rz = (int(v) for v in vres)
+        v = np.ascontiguousarray(vox, dtype=np.uint8).reshape(-1)
+        if v.size != rx * ry * rz:
+            raise ValueError("volume size does not match vres")
+        check(lib().rm_stage_volume(self._h, v.ctypes.data, rx, ry, rz, int(iso_val)))
         self._staged_vres = (rx, ry, rz)
 
     def commit_staged_volume(self):

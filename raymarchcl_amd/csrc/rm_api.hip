@@ -832,15 +832,15 @@ int rm_set_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz
 // ---- animated volumes: the next volume's tables are built while the resident one renders (meshvoxel.clj:85-89
 // make-heatmap-anim feeds core.clj:181-213 a new volume per frame; built inside the frame they cost 2.25 ms per 256^3
 // volume on top of a 4 ms frame).  Two volume states per context: `vol` (resident, rendered from) and `staged`.
-int rm_stage_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz, int iso_val) {
+static int stage_volume(rm_ctx* c, const void* voxels, bool on_host, int rx, int ry, int rz, int iso_val) {
   int rc = check_ctx(c);
   if (rc) return rc;
-  if (!d_voxels) return fail(RM_EINVAL, "d_voxels is NULL");
+  if (!voxels) return fail(RM_EINVAL, "voxels is NULL");
   if (iso_val < 0 || iso_val > 255) return fail(RM_EINVAL, "iso_val = %d", iso_val);
   rc = check_res(rx, ry, rz);
   if (rc) return rc;
   if (!c->peers.empty() || c->parent)
-    return fail(RM_ESTATE, "rm_stage_volume_device: not on a multi-device context (rm_set_volume_device replicates there)");
+    return fail(RM_ESTATE, "rm_stage_volume*: not on a multi-device context (rm_set_volume* replicates there)");
   // the slot: the volume the last commit retired, if nobody else still renders from it
   if (!c->staged || c->staged.use_count() != 1) {
     Volume* v = new (std::nothrow) Volume();
@@ -854,11 +854,22 @@ int rm_stage_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int 
   static std::atomic<unsigned long long> next_staged_generation{1ull << 48};
   v.generation = next_staged_generation.fetch_add(1);
   v.accel_iso = -1;
-  v.d_vox = static_cast<const uint8_t*>(d_voxels);
-  v.rx = rx; v.ry = ry; v.rz = rz;
-  // frames that still read the retired volume's tables were enqueued on the context's stream before ev_back_free
+  v.d_vox = nullptr;
+  v.rx = v.ry = v.rz = 0;
+  // frames that still read the retired volume (its bytes, if it owns them, and its tables) were enqueued on the
+  // context's stream before ev_back_free
   if (c->back_free_pending) HIP_TRY(hipStreamWaitEvent(c->prep_stream, c->ev_back_free, 0));
   c->back_free_pending = false;
+  if (on_host) {  // the bytes go into the slot's own buffer; the call returns once they have been taken
+    const size_t bytes = (size_t)rx * ry * rz;
+    HIP_TRY(v.vox_buf.reserve(bytes));
+    HIP_TRY(hipMemcpyAsync(v.vox_buf.p, voxels, bytes, hipMemcpyHostToDevice, c->prep_stream));
+    HIP_TRY(hipStreamSynchronize(c->prep_stream));
+    v.d_vox = static_cast<const uint8_t*>(v.vox_buf.p);
+  } else {
+    v.d_vox = static_cast<const uint8_t*>(voxels);
+  }
+  v.rx = rx; v.ry = ry; v.rz = rz;
   if (tables_possible(c, v)) {
     rc = enqueue_tables(c, v, iso_val, c->prep_stream, c->ev_s0, c->ev_s1);
     if (rc) { v.d_vox = nullptr; return rc; }
@@ -868,6 +879,12 @@ int rm_stage_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int 
   HIP_TRY(hipEventRecord(c->ev_staged, c->prep_stream));
   c->staged_ready = true;
   return RM_OK;
+}
+int rm_stage_volume_device(rm_ctx* c, const void* d_voxels, int rx, int ry, int rz, int iso_val) {
+  return stage_volume(c, d_voxels, false, rx, ry, rz, iso_val);
+}
+int rm_stage_volume(rm_ctx* c, const uint8_t* voxels, int rx, int ry, int rz, int iso_val) {
+  return stage_volume(c, voxels, true, rx, ry, rz, iso_val);
 }
 
 int rm_commit_staged_volume(rm_ctx* c) {

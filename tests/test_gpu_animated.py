@@ -69,6 +69,27 @@ def test_staged_volume_sequence_is_bit_identical(native, oracle_mod, res, contra
             assert np.array_equal(px.view(np.uint32), want.view(np.uint32)) and np.array_equal(argb, want_argb)
 
 
+def test_staging_from_host_bytes(native):
+    """rm_stage_volume: the bytes are copied into a buffer of the library's (what a JNI caller's direct ByteBuffer
+    gets); the caller may reuse its array at once; frames equal those of rm_set_volume."""
+    vols = [scenes.volume("gyroid", 64), scenes.volume("terrain", 64)]
+    sc = scenes.build("orange_dof_2spp")
+    with native.Context(0) as ref:
+        want = []
+        for v in vols:
+            ref.set_volume(v, (64,) * 3)
+            want.append(ref.render_frame(sc["opts"], sc["mc"], sc["n"]))
+    with native.Context(0) as ctx:
+        ctx.set_volume(vols[1], (64,) * 3)
+        for k in (0, 1, 0):
+            scratch = vols[k].copy()
+            ctx.stage_volume(scratch, (64,) * 3, 32)
+            scratch[:] = 0  # (taken already)
+            ctx.commit_staged_volume()
+            px, argb = ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+            assert np.array_equal(px.view(np.uint32), want[k][0].view(np.uint32)) and np.array_equal(argb, want[k][1]), k
+
+
 def test_staging_another_shape_drops_the_validation(native):
     import torch
 

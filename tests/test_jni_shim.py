@@ -98,4 +98,4 @@ def test_every_entry_point_through_a_stand_in_jnienv(tmp_path, native, oracle_mo
     want, want_argb = gfx950_pin.Checker(oracle_mod, "default").frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], n)
     assert np.array_equal(px, want.view(np.uint32)) and np.array_equal(argb, want_argb)
     assert np.array_equal(px1, want.view(np.uint32)) and np.array_equal(argb1, want_argb)
-    assert checks.tolist() == [1] * 9, (checks.tolist(), r.stderr[-1500:])
+    assert checks.tolist() == [1] * 10, (checks.tolist(), r.stderr[-1500:])
