@@ -84,6 +84,51 @@ __device__ __forceinline__ void central(const uint8_t* __restrict__ vox, const D
   gz = occ(vox, d, iso, x, y, z + 1) - occ(vox, d, iso, x, y, z - 1);
 }
 
+// surf32 in two passes (round 6; one pass read 27 x 7 bytes per hit voxel: 0.33 of the 1.28 ms of a 256^3 build):
+//   1. per cell one byte: occupied (v >= isoVal) ? 1 | the three central differences + 1 in two bits each : 0
+//   2. per hit cell (v > isoVal) the sum over the 27 neighbours of those bytes -- 27 loads instead of 189
+__global__ __launch_bounds__(256) void surf_code_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
+                                                        uint8_t* __restrict__ code) {
+  const long long total = (long long)d.rx * d.ry * d.rz;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    uint8_t c = 0;
+    if (vox[i] >= iso) {
+      const int x = (int)(i % d.rx), y = (int)((i / d.rx) % d.ry), z = (int)(i / ((long long)d.rx * d.ry));
+      int gx, gy, gz;
+      central(vox, d, iso, x, y, z, gx, gy, gz);
+      c = (uint8_t)(1 | (gx + 1) << 1 | (gy + 1) << 3 | (gz + 1) << 5);
+    }
+    code[i] = c;
+  }
+}
+__global__ __launch_bounds__(256) void surf_sum_kernel(const uint8_t* __restrict__ vox, const uint8_t* __restrict__ code,
+                                                       Dim d, int iso, uint32_t* __restrict__ out) {
+  const long long total = (long long)d.rx * d.ry * d.rz;
+  const long long sy = d.rx, sz = (long long)d.rx * d.ry;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int v = vox[i];
+    uint32_t w = (uint32_t)v;
+    if (v > iso) {
+      const int x = (int)(i % d.rx), y = (int)((i / d.rx) % d.ry), z = (int)(i / sz);
+      const int own = code[i];  // (v > isoVal implies occupied)
+      const int gx = ((own >> 1) & 3) - 1, gy = ((own >> 3) & 3) - 1, gz = ((own >> 5) & 3) - 1;
+      int sx = 0, sy_ = 0, sz_ = 0;
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            if (!inb(d, x + dx, y + dy, z + dz)) continue;
+            const int c = code[i + dz * sz + dy * sy + dx];
+            if (c & 1) { sx -= ((c >> 1) & 3) - 1; sy_ -= ((c >> 3) & 3) - 1; sz_ -= ((c >> 5) & 3) - 1; }
+          }
+      w |= (uint32_t)(sx + 32) << 8 | (uint32_t)(sy_ + 32) << 14 | (uint32_t)(sz_ + 32) << 20 |
+           (uint32_t)(gx + 1) << 26 | (uint32_t)(gy + 1) << 28 | (uint32_t)(gz + 1) << 30;
+    }
+    out[i] = w;
+  }
+}
+// (the one-pass form: grids for which the caller has no scratch bytes)
 __global__ __launch_bounds__(256) void surf_kernel(const uint8_t* __restrict__ vox, Dim d, int iso,
                                                    uint32_t* __restrict__ out) {
   const long long total = (long long)d.rx * d.ry * d.rz;
@@ -371,7 +416,7 @@ hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, i
 }
 
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
-                       uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf) {
+                       uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf, uint8_t* d_scratch) {
   const Dim d{rx, ry, rz};
   const long long total = (long long)rx * ry * rz;
   const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
@@ -380,7 +425,12 @@ hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int
     dist_axis_kernel<<<blocks, 256, 0, st>>>(d_dist, d, 1, d_tmp);
     dist_axis_kernel<<<blocks, 256, 0, st>>>(d_tmp, d, 2, d_dist);
   }
-  surf_kernel<<<blocks, 256, 0, st>>>(d_vox, d, iso, d_surf);
+  if (d_scratch) {  // rx*ry*rz bytes nobody needs until this call has finished
+    surf_code_kernel<<<blocks, 256, 0, st>>>(d_vox, d, iso, d_scratch);
+    surf_sum_kernel<<<blocks, 256, 0, st>>>(d_vox, d_scratch, d, iso, d_surf);
+  } else {
+    surf_kernel<<<blocks, 256, 0, st>>>(d_vox, d, iso, d_surf);
+  }
   return hipGetLastError();
 }
 

@@ -226,8 +226,9 @@ static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEven
   HIP_TRY(hipEventRecord(t0, st));
   v.oct_stride = 0;
   if (oct) {
+    // (scratch of the two-pass surf32: the region of table 0, which dist_from_oct_kernel writes last)
     HIP_TRY(rmk::build_accel(st, v.d_vox, v.rx, v.ry, v.rz, iso, nullptr, nullptr,
-                             static_cast<uint32_t*>(v.surf_buf.p)));
+                             static_cast<uint32_t*>(v.surf_buf.p), lin));
     HIP_TRY(rmk::build_octants(st, v.d_vox, v.rx, v.ry, v.rz, iso, lin, bricked));
     v.oct_stride = tbytes;
     v.bricked = bricked;
@@ -235,7 +236,8 @@ static int enqueue_tables(rm_ctx* c, Volume& v, int iso, hipStream_t st, hipEven
     v.bricked = false;
     HIP_TRY(v.tmp_buf.reserve(vox));
     HIP_TRY(rmk::build_accel(st, v.d_vox, v.rx, v.ry, v.rz, iso, lin,
-                             static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p)));
+                             static_cast<uint8_t*>(v.tmp_buf.p), static_cast<uint32_t*>(v.surf_buf.p),
+                             static_cast<uint8_t*>(v.tmp_buf.p)));  // (tmp is free again after the distance passes)
   }
   HIP_TRY(hipEventRecord(t1, st));
   return RM_OK;

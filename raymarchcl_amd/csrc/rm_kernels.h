@@ -68,8 +68,9 @@ hipError_t launch_tonemap(hipStream_t st, const float* d_pixels, const RmOpts* d
                           uint32_t* d_argb, int n, int arith = 0);
 // surf32 of a resident volume for hit threshold `iso` (rm_accel.hip) and -- when d_dist is not
 // null -- dist8 alone by separable passes (d_tmp: scratch of the volume's size)
+// d_scratch (nullable): rx*ry*rz bytes that may be overwritten -- surf32 is then built in two passes (27 instead of 189 loads per hit voxel)
 hipError_t build_accel(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
-                       uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf);
+                       uint8_t* d_dist, uint8_t* d_tmp, uint32_t* d_surf, uint8_t* d_scratch = nullptr);
 // the 8 directional tables (d_dist9 = 9 * volume bytes: tables 1..8) and dist8 derived from
 // them (table 0); no scratch
 hipError_t build_octants(hipStream_t st, const uint8_t* d_vox, int rx, int ry, int rz, int iso,
