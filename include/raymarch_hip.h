@@ -150,7 +150,7 @@ int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int 
  * heat-map animation rewrites its v-buf every frame) call this before the next frame:
  * the tables are rebuilt and records accepted by rm_check_device_opts must be checked again. */
 /* ANIMATED VOLUMES -- the reference's heat-map animation (meshvoxel.clj:85-89 make-heatmap-anim -> core.clj:181-213)
- * renders a NEW volume every frame; the tables derived from a volume (1.3 ms at 256^3, 6.7 ms at 512^3, 41 ms at
+ * renders a NEW volume every frame; the tables derived from a volume (1.1 ms at 256^3, 5.4 ms at 512^3, 31 ms at
  * 1024^3) would be built inside every frame, with a host wait.  rm_stage_volume_device enqueues their build for the
  * NEXT volume (borrowed device bytes, as rm_set_volume_device; iso_val = the isoVal its frames will use) on a stream
  * of the library's own and returns at once; rm_commit_staged_volume makes that volume the resident one for everything
@@ -160,7 +160,7 @@ int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int 
  * host never waits for it.  What it does not: beside a frame kernel that fills the chip the build's workgroups (4
  * wavefronts, 14 KB LDS) find no room -- the frame's one-wavefront workgroups refill every slot that frees, stream
  * priority does not change that -- and the chain ends after the frame (measured at 256^3, blocking frames: period
- * 5.39 ms staged, 5.60 ms serial, 4.0 ms the frame alone; bench.py `animated_volume`).  The volume a commit retires becomes the next staging slot; it is
+ * 5.17 ms staged, 5.33 ms serial, 4.0 ms the frame alone; bench.py `animated_volume`).  The volume a commit retires becomes the next staging slot; it is
  * overwritten only after the frames that read it (the library orders that itself).  A commit keeps what
  * rm_check_device_opts accepted when the new volume has the old one's resolution.  Single-device contexts only;
  * contexts that shared the old volume keep rendering it.  Pixels are those of rm_set_volume_device + the same frame. */

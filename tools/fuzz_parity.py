@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this much wall time (0: run all cases)")
     ap.add_argument("--passes", default="1,2,4,3,8,16", help="pass counts the cases draw from (default: the list the "
                     "earlier rounds' seeds were logged with; add 25,32 for runs that fill 32 pass slots per wavefront)")
+    ap.add_argument("--ao-max", type=int, default=8, help="largest aoIter the record overrides draw (default 8 = the "
+                    "logged seeds' stream; 20 exercises the chunked AO exchange of the 256^3 / 512^3 frame kernels)")
+    ap.add_argument("--grids", default="", help="comma-separated cubic gyroid edges to draw the volume from instead "
+                    "of the default mix (e.g. 256 or 256,512: the table layouts with the edge compiled in)")
     ap.add_argument("--only", type=int, default=-1, help="replay the random stream but render only this case")
     ap.add_argument("--dump", default="", help="with --only: save the case's inputs and both results to this .npz")
     args = ap.parse_args()
@@ -42,6 +46,8 @@ def main():
     pass_counts = [int(v) for v in args.passes.split(",")]
     vols = [("gyroid", 64), ("terrain", 64), ("blobs", 64), ("gyroid-crop", (64, 40, 48)), ("gyroid", 32),
             ("gyroid", 128), ("gyroid", 256), ("terrain", 128)]
+    if args.grids:
+        vols = [("gyroid", int(v)) for v in args.grids.split(",")]
     sparse = gen.make_blob_volume(64, radius=(0.01, 0.03))
     mats = sorted(materials.presets)
     bad = skipped = undefined_dev = 0
@@ -66,7 +72,7 @@ def main():
                     fov=float(rng.uniform(40, 120)), dof=float(rng.choice([0.0, 0.001, 0.025, 0.1])))
         over = {}
         if rng.random() < 0.5:
-            pool = dict(aoIter=int(rng.integers(0, 9)), aoStepDist=float(rng.uniform(0.01, 0.3)),
+            pool = dict(aoIter=int(rng.integers(0, args.ao_max + 1)), aoStepDist=float(rng.uniform(0.01, 0.3)),
                         aoAmp=float(rng.uniform(0.0, 0.6)), voxelSize=float(rng.uniform(0.001, 0.05)),
                         groundY=float(rng.uniform(0.3, 1.5)), maxVoxelIter=int(rng.integers(8, 300)),
                         lightScatter=float(rng.uniform(0.0, 0.5)), shadowBias=float(rng.uniform(0.01, 0.3)),
