@@ -130,6 +130,8 @@ struct FrameArgs {
   unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int rows_desc;                       // XCD-aware order: tile rows dispatched bottom to top
+  int rows_real, full_groups, tail_share;  // XCD-aware order: tile rows of the launch, whole groups of 8 among them, blocks of the
+                                       // last (< 8) rows per XCD (see frame_block)
   int band_r0, band_r1;                // ... and, when band_r1 > band_r0, the tile rows [band_r0, band_r1) FIRST: the rows whose
                                        // primary rays can meet the clip box (rm_api.hip volume_band), then the rows below them,
                                        // the rows above them -- sky in the reference's scenes -- last
@@ -170,22 +172,35 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   long long lb = hw_block;
   if (a.bpr > 0) {
     const long long m = lb >> 3, k = lb & 7;
+    // The dispatcher's assignment of workgroups to XCDs is STATIC (workgroup i -> XCD i % 8), so an XCD's share of the
+    // frame is fixed by this mapping.  Whole groups of 8 tile rows give every XCD one row each.  The last r < 8 rows used to
+    // go to r of the XCDs as whole rows -- at 720 lines (90 tile rows) two XCDs rendered 12 rows and six 11, and the frame
+    // took exactly as long as one of 96 rows (round 6: 3.97 ms for 712 .. 768 lines, 3.72 ms for 704).  Now the blocks of
+    // those r rows are dealt to the eight XCDs in equal contiguous shares.
+    const long long full = (long long)a.full_groups * a.bpr;
+    long long row, col;  // row in dispatch order, block within the row
+    if (m < full) {
+      row = (m / a.bpr) * 8 + k;
+      col = m % a.bpr;
+    } else {
+      const long long j = k * (long long)a.tail_share + (m - full);
+      if (m - full >= a.tail_share || j >= (long long)(a.rows_real - 8 * a.full_groups) * a.bpr) return;  // (padding of the shares)
+      row = 8ll * a.full_groups + j / a.bpr;
+      col = j % a.bpr;
+    }
     // ... BOTTOM ROWS FIRST (round 5): a frame that is waited for ends with the tail of its last wavefronts, and in
-    // the reference's scenes the top rows are sky -- short wavefronts, the cheapest possible tail.  One blocking frame
-    // -0.5 %, a rank's share of an 8-way partition -12 % (0.73 -> 0.64 ms: the compute side of 8 GPUs 5.5x -> 6.2x),
-    // config 5 -3.5 %, config 3 +1.1 %, config 4 +0.2 % (RAYMARCH_ROW_ORDER=asc restores the old order).
-    const long long rows = (long long)gridDim.x / a.bpr;  // (padded to a multiple of 8: surplus blocks exit at once)
-    const long long row = (m / a.bpr) * 8 + k;
-    // ... THE ROWS THAT SEE THE VOLUME FIRST (round 6): the costly wavefronts are the ones whose rays walk the tables; they
-    // go out first (bottom to top), then the ground rows below them, the rows above them last -- the longest jobs first and
-    // the shortest as the tail.  The band comes from the clip box's projection through the camera of record 0 (host).
+    // the reference's scenes the top rows are the cheapest.  One blocking frame -0.5 %, a rank's share of an 8-way partition
+    // -12 %, config 5 -3.5 %, config 3 +1.1 %, config 4 +0.2 % (RAYMARCH_ROW_ORDER=asc restores the old order).
+    const long long rows = a.rows_real;
+    // ... A BAND OF ROWS FIRST (round 6, opt-in: RAYMARCH_ROW_ORDER=band / RAYMARCH_ROW_BAND): those rows bottom to top, then
+    // the rows below them, the rows above them last (rm_api.hip volume_band)
     long long at_row = a.rows_desc ? rows - 1 - row : row;
     const long long nb = (long long)a.band_r1 - a.band_r0;
     if (nb > 0) {
-      const long long below = rows - a.band_r1;  // (incl. the padding rows, whose blocks exit at once)
+      const long long below = rows - a.band_r1;
       at_row = row < nb ? a.band_r1 - 1 - row : (row < nb + below ? rows - 1 - (row - nb) : a.band_r0 - 1 - (row - nb - below));
     }
-    lb = at_row * a.bpr + (m % a.bpr);
+    lb = at_row * a.bpr + col;
   }
   // wavefronts of a tile are consecutive: tile slot = w / pp, sub-block = w % pp
   const long long slot = lb >> pp_log2;
@@ -467,7 +482,7 @@ int choose_pass_pack(int passes, int max_log2, int waste_pct) {
 }
 
 // grid of a frame launch: one wavefront per workgroup; *bpr_out = blocks per tile row of the XCD-aware order (0: plain)
-static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out) {
+static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out, int* rows_out = nullptr) {
   const TileGeom g = tile_geom(f.resx, f.n);
   const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
   const long long my_tiles =
@@ -483,8 +498,11 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
   if (f.xcd_rows && g.tiles_x % tile_stride == 0 && f.tile_first < tile_stride) {
     const int bpr = (int)((long long)(g.tiles_x / tile_stride) << pp_log2);
     const long long rows = (blocks + bpr - 1) / bpr;
-    blocks = ((rows + 7) / 8) * 8 * bpr;  // pad to groups of 8 rows; surplus blocks exit at once
+    // whole groups of 8 rows (one row per XCD) + the blocks of the last rows in eight equal shares (frame_block)
+    const long long groups = rows / 8, tail_blocks = (rows % 8) * bpr, share = (tail_blocks + 7) / 8;
+    blocks = groups * 8 * bpr + 8 * share;
     if (bpr_out) *bpr_out = bpr;
+    if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; }
   }
   return blocks;
 }
@@ -494,9 +512,11 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
   int bpr = 0, pp_log2 = 0;
-  const long long blocks = frame_grid(f, &bpr, &pp_log2);
+  int rows3[3] = {0, 0, 0};
+  const long long blocks = frame_grid(f, &bpr, &pp_log2, rows3);
   if (blocks == 0) return hipSuccess;
   FrameArgs a;
+  a.rows_real = rows3[0]; a.full_groups = rows3[1]; a.tail_share = rows3[2];
   a.vox = f.vox;
   a.dist8 = f.accel.dist;
   a.surf32 = f.accel.surf;
@@ -513,8 +533,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.rows_desc = f.rows_desc ? 1 : 0;
   a.band_r0 = a.band_r1 = 0;
   if (bpr > 0 && f.rows_desc && f.band_hi > f.band_lo) {  // image-height fractions -> rows of this launch's grid
-    const long long my_blocks = (long long)tpp << pp_log2;
-    const long long rows_real = (my_blocks + bpr - 1) / bpr;
+    const long long rows_real = a.rows_real;
     long long r0 = (long long)(f.band_lo * (double)rows_real), r1 = (long long)(f.band_hi * (double)rows_real) + 1;
     r0 = r0 < 0 ? 0 : r0;
     r1 = r1 > rows_real ? rows_real : r1;
