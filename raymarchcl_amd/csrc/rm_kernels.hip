@@ -130,6 +130,7 @@ struct FrameArgs {
   unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int rows_desc;                       // XCD-aware order: tile rows dispatched bottom to top
+  int xcd2d;                           // XCD-aware order in 2-D units (frame_block): an XCD's unit = 2 tile rows x 1/8 of their width
   int rows_real, full_groups, tail_share;  // XCD-aware order: tile rows of the launch, whole groups of 8 among them, blocks of the
                                        // last (< 8) rows per XCD (see frame_block)
   int band_r0, band_r1;                // ... and, when band_r1 > band_r0, the tile rows [band_r0, band_r1) FIRST: the rows whose
@@ -179,7 +180,25 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     // those r rows are dealt to the eight XCDs in equal contiguous shares.
     const long long full = (long long)a.full_groups * a.bpr;
     long long row, col;  // row in dispatch order, block within the row
-    if (m < full) {
+    if (a.xcd2d) {
+      // 2-D UNITS (round 6): XCD k renders, of the row pair rp, the eighth (k - rp) mod 8 of its width -- two tile rows x 1/8
+      // row, the two rows interleaved tile by tile.  Every XCD gets exactly one unit of every row pair (and an eighth of an
+      // odd last row): equal shares by construction, no padding; and the wavefronts an XCD has in flight cover a compact
+      // patch of the image (config 2: 160 x 16 pixels instead of a 448 x 8 strip), whose rays share more table lines in the
+      // XCD's L2: config 2 3.78 -> 3.69 ms (units of 1 / 3 rows, or of 1/16 / 1/32 of the width: slower).
+      const long long sw = a.bpr >> 3, per_unit = 2 * sw, pairs = a.rows_real >> 1;
+      const long long rp = m / per_unit;
+      if (rp < pairs) {
+        const long long w = m - rp * per_unit, chunk = w >> pp_log2;
+        row = 2 * rp + (chunk & 1);
+        col = ((k - rp) & 7) * sw + ((chunk >> 1) << pp_log2) + (w & (pp - 1));
+      } else {
+        const long long w = m - pairs * per_unit;
+        if (w >= sw || !(a.rows_real & 1)) return;
+        row = a.rows_real - 1;
+        col = ((k - rp) & 7) * sw + w;
+      }
+    } else if (m < full) {
       row = (m / a.bpr) * 8 + k;
       col = m % a.bpr;
     } else {
@@ -502,7 +521,12 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
     const long long groups = rows / 8, tail_blocks = (rows % 8) * bpr, share = (tail_blocks + 7) / 8;
     blocks = groups * 8 * bpr + 8 * share;
     if (bpr_out) *bpr_out = bpr;
-    if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; }
+    if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; rows_out[3] = 0; }
+    // 2-D units: the stripes (1/8 of a row) must hold whole tiles
+    if (f.xcd_2d && (g.tiles_x / tile_stride) % 8 == 0) {
+      blocks = rows * bpr;
+      if (rows_out) rows_out[3] = 1;
+    }
   }
   return blocks;
 }
@@ -512,11 +536,11 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
   int bpr = 0, pp_log2 = 0;
-  int rows3[3] = {0, 0, 0};
+  int rows3[4] = {0, 0, 0, 0};
   const long long blocks = frame_grid(f, &bpr, &pp_log2, rows3);
   if (blocks == 0) return hipSuccess;
   FrameArgs a;
-  a.rows_real = rows3[0]; a.full_groups = rows3[1]; a.tail_share = rows3[2];
+  a.rows_real = rows3[0]; a.full_groups = rows3[1]; a.tail_share = rows3[2]; a.xcd2d = rows3[3];
   a.vox = f.vox;
   a.dist8 = f.accel.dist;
   a.surf32 = f.accel.surf;
