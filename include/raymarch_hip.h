@@ -160,7 +160,7 @@ int rm_set_volume_device(rm_ctx* ctx, const void* d_voxels, int rx, int ry, int 
  * host never waits for it.  What it does not: beside a frame kernel that fills the chip the build's workgroups (4
  * wavefronts, 14 KB LDS) find no room -- the frame's one-wavefront workgroups refill every slot that frees, stream
  * priority does not change that -- and the chain ends after the frame (measured at 256^3, blocking frames: period
- * 5.06 ms staged, 5.22 ms serial, 3.8 ms the frame alone; bench.py `animated_volume`).  The volume a commit retires becomes the next staging slot; it is
+ * 5.00 ms staged, 5.15 ms serial, 3.7 ms the frame alone; bench.py `animated_volume`).  The volume a commit retires becomes the next staging slot; it is
  * overwritten only after the frames that read it (the library orders that itself).  A commit keeps what
  * rm_check_device_opts accepted when the new volume has the old one's resolution.  Single-device contexts only;
  * contexts that shared the old volume keep rendering it.  Pixels are those of rm_set_volume_device + the same frame. */
