@@ -102,7 +102,7 @@ struct rm_ctx {
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
-  int xcd_2d_forced = -1;    // RAYMARCH_XCD_2D=0/1: whole tile rows per XCD (rounds 1-5) / 2-D units (default: 2-D unless the tables exceed 4 GiB)
+  int xcd_2d_forced = -1;    // RAYMARCH_XCD_2D=0: whole tile rows per XCD (rounds 1-5); 1/2/4/8: 2-D units of 1/8 .. 1/64 row; default: chosen per launch
   bool rows_desc = true;     // RAYMARCH_ROW_ORDER=asc: tile rows top to bottom (rounds 2-4); default bottom to top
   bool rows_band = false;    // RAYMARCH_ROW_ORDER=band: the rows where the clip box covers most of the width first (volume_band,
                              // round 6).  Opt-in: no band exists at BASELINE's camera (the box fills the view), and at three
@@ -493,10 +493,7 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.tile_first = out.tile_first; f.tile_stride = out.tile_stride;
     f.pp_log2 = pp_log2;
     f.xcd_rows = c->xcd_rows;
-    // (2-D units per XCD: config 2 -2.3 %, config 3 -1.2 %, config 4 -0.6 %, config 1 -2.9 %; the 1024^3 case, whose tables are
-    //  35x the L2s and 36x the Infinity Cache, +0.6 %: whole rows stay there -- unless RAYMARCH_XCD_2D says otherwise)
-    f.xcd_2d = c->xcd_2d_forced >= 0 ? c->xcd_2d_forced == 1
-                                     : (sdf_frame || (size_t)c->vol->rx * c->vol->ry * c->vol->rz * 9 < ((size_t)4 << 30));
+    f.xcd_2d = c->xcd_2d_forced;  // (-1: the launcher picks the unit width, rm_kernels.hip frame_grid)
     f.rows_desc = c->rows_desc;
     if (c->band_fixed_hi > c->band_fixed_lo) { f.band_lo = c->band_fixed_lo; f.band_hi = c->band_fixed_hi; }
     else if (c->rows_band && !sdf_frame) volume_band(host_recs[0], &f.band_lo, &f.band_hi);
@@ -610,7 +607,7 @@ static int create_one(int device_id, rm_ctx** out) {
   c->use_octants = !(oc && oc[0] == '0');
   const char* xr = getenv("RAYMARCH_XCD_ROWS");
   if (xr) c->xcd_rows = xr[0] != '0';
-  if (const char* x2 = getenv("RAYMARCH_XCD_2D")) c->xcd_2d_forced = x2[0] != '0' ? 1 : 0;
+  if (const char* x2 = getenv("RAYMARCH_XCD_2D")) c->xcd_2d_forced = (x2[0] >= '0' && x2[0] <= '8') ? x2[0] - '0' : 1;
   const char* ro = getenv("RAYMARCH_ROW_ORDER");
   if (ro) c->rows_desc = !(ro[0] == 'a');
   if (ro) c->rows_band = ro[0] == 'b';  // "desc" (default) / "band" / "asc"

@@ -130,7 +130,8 @@ struct FrameArgs {
   unsigned log2res;                    // table LAYOUT 2: edge of the cubic grid = 1 << log2res
   int accumulate;                      // 0: the accumulator starts at zero (first launch of a frame)
   int rows_desc;                       // XCD-aware order: tile rows dispatched bottom to top
-  int xcd2d;                           // XCD-aware order in 2-D units (frame_block): an XCD's unit = 2 tile rows x 1/8 of their width
+  int xcd2d;                           // XCD-aware order in 2-D units (frame_block): n > 0 = an XCD renders n units of every pair of
+                                       // tile rows, each 2 rows x 1/(8 n) of their width; 0 = whole tile rows per XCD
   int rows_real, full_groups, tail_share;  // XCD-aware order: tile rows of the launch, whole groups of 8 among them, blocks of the
                                        // last (< 8) rows per XCD (see frame_block)
   int band_r0, band_r1;                // ... and, when band_r1 > band_r0, the tile rows [band_r0, band_r1) FIRST: the rows whose
@@ -181,22 +182,24 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     const long long full = (long long)a.full_groups * a.bpr;
     long long row, col;  // row in dispatch order, block within the row
     if (a.xcd2d) {
-      // 2-D UNITS (round 6): XCD k renders, of the row pair rp, the eighth (k - rp) mod 8 of its width -- two tile rows x 1/8
-      // row, the two rows interleaved tile by tile.  Every XCD gets exactly one unit of every row pair (and an eighth of an
-      // odd last row): equal shares by construction, no padding; and the wavefronts an XCD has in flight cover a compact
-      // patch of the image (config 2: 160 x 16 pixels instead of a 448 x 8 strip), whose rays share more table lines in the
-      // XCD's L2: config 2 3.78 -> 3.69 ms (units of 1 / 3 rows, or of 1/16 / 1/32 of the width: slower).
-      const long long sw = a.bpr >> 3, per_unit = 2 * sw, pairs = a.rows_real >> 1;
-      const long long rp = m / per_unit;
+      // 2-D UNITS (round 6): XCD k renders, of the row pair rp, the stripes (k - rp) mod 8 + 8 j (j < n) of the 8 n its width
+      // is cut into -- two tile rows x 1/(8 n) row per unit, the two rows interleaved tile by tile.  Every XCD gets exactly n
+      // units of every row pair (and an eighth of an odd last row): equal shares by construction, no padding; and the
+      // wavefronts an XCD has in flight cover compact patches of the image (config 2, n = 1: 160 x 16 pixels instead of a
+      // 448 x 8 strip), whose rays share more table lines in the XCD's L2: config 2 3.78 -> 3.69 ms.  n is chosen per
+      // launch (frame_grid): config 2 is fastest at 1, config 3 at 2 (9.74 -> 9.22 ms), config 5 31.65 instead of 32.6 ms with
+      // whole rows; units of 1 or 3 rows: slower.
+      const long long nsu = a.xcd2d, sw = a.bpr / (8 * nsu), per_unit = 2 * sw, pairs = a.rows_real >> 1;
+      const long long ul = m / per_unit, rp = ul / nsu, jj = ul - rp * nsu;
       if (rp < pairs) {
-        const long long w = m - rp * per_unit, chunk = w >> pp_log2;
+        const long long w = m - ul * per_unit, chunk = w >> pp_log2;
         row = 2 * rp + (chunk & 1);
-        col = ((k - rp) & 7) * sw + ((chunk >> 1) << pp_log2) + (w & (pp - 1));
+        col = (((k - rp) & 7) + 8 * jj) * sw + ((chunk >> 1) << pp_log2) + (w & (pp - 1));
       } else {
-        const long long w = m - pairs * per_unit;
-        if (w >= sw || !(a.rows_real & 1)) return;
+        const long long w = m - pairs * nsu * per_unit;  // an odd last row: 1/8 of it per XCD
+        if (w >= sw * nsu || !(a.rows_real & 1)) return;
         row = a.rows_real - 1;
-        col = ((k - rp) & 7) * sw + w;
+        col = ((k - rp) & 7) * (sw * nsu) + w;
       }
     } else if (m < full) {
       row = (m / a.bpr) * 8 + k;
@@ -522,10 +525,24 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
     blocks = groups * 8 * bpr + 8 * share;
     if (bpr_out) *bpr_out = bpr;
     if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; rows_out[3] = 0; }
-    // 2-D units: the stripes (1/8 of a row) must hold whole tiles
-    if (f.xcd_2d && (g.tiles_x / tile_stride) % 8 == 0) {
-      blocks = rows * bpr;
-      if (rows_out) rows_out[3] = 1;
+    // 2-D units: stripes must hold whole tiles.  Unit width 1/(8 nsu) of a row; auto (xcd_2d < 0): the narrowest unit that
+    // still holds at least half of the wavefronts an XCD has in flight (7 per SIMD x 4 x 32 CUs = 896) -- measured: config 2
+    // (640 wavefronts per unit at nsu = 1, 320 at 2) is fastest at 1, config 3 (960 / 480) at 2 (-4.6 % against 1), config 4
+    // (1920 / 960 / 480) within 0.4 % for 1 / 2 / 4, config 5 (1920 / 960) -1.2 .. -3 % against whole rows either way
+    {
+      const int tpr = g.tiles_x / tile_stride;
+      int nsu = f.xcd_2d;
+      if (nsu < 0) {
+        nsu = 0;
+        if (tpr % 8 == 0) {
+          nsu = 1;
+          while (nsu < 8 && tpr % (16 * nsu) == 0 && 2ll * (tpr / (16 * nsu)) * (1ll << pp_log2) >= 448) nsu *= 2;
+        }
+      }
+      if (nsu > 0 && tpr % (8 * nsu) == 0) {
+        blocks = rows * bpr;
+        if (rows_out) rows_out[3] = nsu;
+      }
     }
   }
   return blocks;

@@ -345,6 +345,32 @@ def test_walk_limits_with_unusual_records(oracle_mod, native, name, over):
     assert ok.mean() > 0.5
 
 
+@pytest.mark.parametrize("w,h,spp", [(1280, 88, 2), (1024, 40, 16), (768, 24, 3)])
+def test_frame_is_independent_of_the_xcd_unit_width(native, monkeypatch, w, h, spp):
+    """The XCD-aware dispatch order (rm_kernels.hip frame_block) is a permutation of the launch's workgroups: whole tile
+    rows per XCD, 2-D units of 1/8 .. 1/64 of a row pair, the width the launcher picks by itself and the plain block order
+    must render the same frame bit for bit -- with an odd number of tile rows (88 lines = 11 rows), with widths whose rows
+    hold 8 / 16 / 32 / 64 tiles per stripe or not (a unit width the row cannot hold falls back to whole rows), and with
+    several passes per wavefront.  The plain order is the one every other test checks against the oracle."""
+    sc = scenes.build(dict(vol="gyroid", vres=64, w=w, h=h, iter=spp, mat="orange-stripes", theta=-45, dist=2.25, dof=0.025))
+    frames = {}
+    for key, env in (("plain", {"RAYMARCH_XCD_ROWS": "0"}), ("auto", {}), ("0", {"RAYMARCH_XCD_2D": "0"}), ("1", {"RAYMARCH_XCD_2D": "1"}),
+                     ("2", {"RAYMARCH_XCD_2D": "2"}), ("4", {"RAYMARCH_XCD_2D": "4"}), ("8", {"RAYMARCH_XCD_2D": "8"}),
+                     ("2asc", {"RAYMARCH_XCD_2D": "2", "RAYMARCH_ROW_ORDER": "asc"})):
+        for k in ("RAYMARCH_XCD_ROWS", "RAYMARCH_XCD_2D", "RAYMARCH_ROW_ORDER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with native.Context(0) as ctx:
+            ctx.set_volume(sc["vox"], sc["vres"])
+            px, argb = ctx.render_frame(sc["opts"], sc["mc"], sc["n"])
+        frames[key] = (px.view(np.uint32).copy(), argb.copy())
+    assert len(np.unique(frames["plain"][0])) > 1000
+    for key, (px, argb) in frames.items():
+        assert np.array_equal(px, frames["plain"][0]), key
+        assert np.array_equal(argb, frames["plain"][1]), key
+
+
 def test_tables_beyond_4_gib(native, oracle_mod):
     """1024^3: the nine distance tables span 9 GiB, so the directional ones are reached
     through 64-bit offsets.  Volume generated on the device, one small pass == oracle."""
