@@ -98,12 +98,11 @@ struct rm_ctx {
   hipEvent_t ev_back_free = nullptr;  // stream: every frame that read the volume retired by the last commit has been enqueued before it
   hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr;  // timed: the staged build
   bool staged_ready = false, back_free_pending = false, staged_timing = false;
-  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, sdfq_buf, dyn_buf;
+  DevBuf mc_buf, opts_buf, pix_buf, argb_buf, tile_buf, atile_buf, cnt_buf, prim_a, prim_b, prim_o, gen_buf, sdf_buf, sdfq_buf;
   int sdf_rx = 0, sdf_ry = 0, sdf_rz = 0;  // quality mode: resident float distance field
   bool use_octants = true;   // RAYMARCH_OCTANTS=0: dist8 only (A/B)
   bool xcd_rows = true;      // RAYMARCH_XCD_ROWS=0: plain block order
   int xcd_2d_forced = -1;    // RAYMARCH_XCD_2D=0: whole tile rows per XCD (rounds 1-5); 1/2/4/8: 2-D units of 1/8 .. 1/64 row; default: chosen per launch
-  bool xcd_dyn = false;      // RAYMARCH_XCD_DYN=1: the 2-D units dealt to the XCDs at run time (rm_kernels.hip claim_unit)
   bool rows_desc = true;     // RAYMARCH_ROW_ORDER=asc: tile rows top to bottom (rounds 2-4); default bottom to top
   bool rows_band = false;    // RAYMARCH_ROW_ORDER=band: the rows where the clip box covers most of the width first (volume_band,
                              // round 6).  Opt-in: no band exists at BASELINE's camera (the box fills the view), and at three
@@ -496,7 +495,6 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.xcd_rows = c->xcd_rows;
     f.xcd_2d = c->xcd_2d_forced;  // (-1: the launcher picks the unit width, rm_kernels.hip frame_grid)
     f.rows_desc = c->rows_desc;
-    if (c->xcd_dyn && c->dyn_buf.reserve(256 << 10) == hipSuccess) { f.dyn_ctl = static_cast<uint32_t*>(c->dyn_buf.p); f.dyn_ctl_bytes = c->dyn_buf.cap; }
     if (c->band_fixed_hi > c->band_fixed_lo) { f.band_lo = c->band_fixed_lo; f.band_hi = c->band_fixed_hi; }
     else if (c->rows_band && !sdf_frame) volume_band(host_recs[0], &f.band_lo, &f.band_hi);
     f.accumulate = i0 > 0;
@@ -610,7 +608,6 @@ static int create_one(int device_id, rm_ctx** out) {
   const char* xr = getenv("RAYMARCH_XCD_ROWS");
   if (xr) c->xcd_rows = xr[0] != '0';
   if (const char* x2 = getenv("RAYMARCH_XCD_2D")) c->xcd_2d_forced = (x2[0] >= '0' && x2[0] <= '8') ? x2[0] - '0' : 1;
-  if (const char* xd = getenv("RAYMARCH_XCD_DYN")) c->xcd_dyn = xd[0] == '1';
   const char* ro = getenv("RAYMARCH_ROW_ORDER");
   if (ro) c->rows_desc = !(ro[0] == 'a');
   if (ro) c->rows_band = ro[0] == 'b';  // "desc" (default) / "band" / "asc"
@@ -681,7 +678,7 @@ void rm_destroy(rm_ctx* c) {
   for (const void* h : c->host_bufs) (void)hipHostUnregister(const_cast<void*>(h));
   c->host_bufs.clear();
   DevBuf* bufs[] = {&c->mc_buf, &c->opts_buf, &c->pix_buf, &c->argb_buf, &c->tile_buf, &c->cnt_buf,
-                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->sdfq_buf, &c->atile_buf, &c->dyn_buf};
+                    &c->prim_a, &c->prim_b, &c->prim_o, &c->gen_buf, &c->sdf_buf, &c->sdfq_buf, &c->atile_buf};
   for (DevBuf* b : bufs) b->release();
   c->vol.reset();
   for (hipEvent_t ev : c->ev_ring)

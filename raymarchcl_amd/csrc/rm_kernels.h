@@ -45,8 +45,6 @@ struct FrameLaunch {
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
   int xcd_2d = -1;                 // with xcd_rows: 2-D units per XCD: 2 tile rows x 1/(8 n) of the row, n units per row pair (n = 1, 2, 4, 8); 0 = whole rows; -1 = chosen by the launcher
-  uint32_t* dyn_ctl = nullptr;     // with 2-D units: device words for dealing the units at run time (nullptr: fixed shares), and
-  size_t dyn_ctl_bytes = 0;        // their size: 128 B + 4 B per group of wavefronts (9/8 of the units)
   bool rows_desc = true;           // with xcd_rows: tile rows dispatched bottom to top (the top rows -- sky -- make the shortest tail)
   // with rows_desc: the part of the image height (fractions, 0 = top) whose rows are dispatched FIRST -- the rows that can see
   // the clip box (rm_api.hip volume_band); band_hi <= band_lo: none

@@ -132,8 +132,6 @@ struct FrameArgs {
   int rows_desc;                       // XCD-aware order: tile rows dispatched bottom to top
   int xcd2d;                           // XCD-aware order in 2-D units (frame_block): n > 0 = an XCD renders n units of every pair of
                                        // tile rows, each 2 rows x 1/(8 n) of their width; 0 = whole tile rows per XCD
-  uint32_t* dyn;                       // 2-D units dealt at RUN time (frame_block claim_unit): [0] next unit, [32 + k S + u] the unit that
-  int dyn_units, dyn_slots;            // XCD k's u-th group of wavefronts renders; zeroed before the launch.  Units, S = groups per XCD
   int rows_real, full_groups, tail_share;  // XCD-aware order: tile rows of the launch, whole groups of 8 among them, blocks of the
                                        // last (< 8) rows per XCD (see frame_block)
   int band_r0, band_r1;                // ... and, when band_r1 > band_r0, the tile rows [band_r0, band_r1) FIRST: the rows whose
@@ -159,93 +157,8 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
 // across the body of another, and the kernel has no loop over groups of passes.
 // ARITH: the arithmetic contract, rmk::ArithOf (rm_math.hpp): 0 = OpenCL CPU device arithmetic and casts, 1 = the same
 // with the GPU lowering of the seed casts, 2 / 3 = ROCm's OpenCL library on this GPU, strict / default reference build
-#ifdef RM_XCD_CLOCK
-// DIAGNOSTIC BUILD ONLY (tools/ab_build.py clock=-DRM_XCD_CLOCK, tools/xcd_clock.py): when each XCD started and finished its share
-// of the frame kernel's launches, on the 100 MHz constant clock.  [x]: first start, [16 + x]: last end, [32 + x]: sum of the
-// wavefronts' lifetimes, [48 + x]: wavefronts (low 32 bits) and those whose block index mod 8 is NOT x (high 32 bits).
-__device__ unsigned long long g_xcd_clock[96];  // ... [64 + x]: time the wavefronts spent in claim_unit, [80 + x]: wavefronts that found no unit
-// (asm that is not volatile: behind wall_clock64() the compiler treats memory as clobbered and the uniform loads of the whole
-//  kernel become vector loads, see claim_unit -- the first version of this diagnostic ran 47 % slower than the product)
-__device__ __forceinline__ unsigned long long xcd_clock_now(unsigned after) {
-  unsigned long long t;
-  asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0) ; after %1" : "=s"(t) : "s"(after));
-  return t;
-}
-__device__ __forceinline__ void xcd_clock_note(unsigned long long t0, unsigned claim_info) {
-  const unsigned long long t1 = wall_clock64();
-  if ((threadIdx.x & 63) == 0) {
-    const unsigned x = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
-    atomicMin(&g_xcd_clock[x], t0);
-    atomicMax(&g_xcd_clock[16 + x], t1);
-    atomicAdd(&g_xcd_clock[32 + x], t1 - t0);
-    atomicAdd(&g_xcd_clock[48 + x], (blockIdx.x & 7) == x ? 1ull : (1ull << 32) + 1ull);
-    atomicAdd(&g_xcd_clock[64 + x], (unsigned long long)(claim_info >> 1));
-    atomicAdd(&g_xcd_clock[80 + x], (unsigned long long)(claim_info & 1u));
-  }
-}
-#endif
-
-// Which 2-D unit does the u-th group of XCD k's wavefronts render?  The first wavefront of the group to arrive takes the next
-// unit off the launch's counter and posts it; the others read it (0 = nobody yet, 1 = being claimed, g + 2 = unit g).  A
-// wavefront that waits waits for one that is already running.  The counter is shared by the eight XCDs (agent scope).
-// The four accesses are the instructions clang emits for relaxed agent-scope atomics on gfx950, written as asm that is neither
-// volatile nor clobbers memory: as builtins (or volatile asm) they make every later uniform load of the kernel (the render
-// options, 800 scalar loads) a vector load -- the pass that marks loads as not clobbered gives up behind them -- and the
-// allocator answers with 101 spilled VGPRs instead of 23.  Nothing else in the kernel touches these words; each statement
-// depends on the result of the one before, and `turn` keeps the loads of the waiting loop apart.
-__device__ __forceinline__ uint32_t ctl_load(const uint32_t* p, uint32_t turn) {
-  uint32_t v;
-  asm("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0) ; turn %2" : "=&v"(v) : "v"(p), "s"(turn));
-  return v;
-}
-__device__ __forceinline__ uint32_t ctl_load_later(const uint32_t* p, uint32_t turn) {
-  uint32_t v;
-  asm("s_sleep 4\n\tglobal_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0) ; turn %2" : "=&v"(v) : "v"(p), "s"(turn));
-  return v;
-}
-__device__ __forceinline__ uint32_t ctl_cas(uint32_t* p, uint32_t expect, uint32_t value) {
-  uint32_t v;
-  const unsigned long long both = ((unsigned long long)expect << 32) | value;
-  asm("global_atomic_cmpswap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(both));
-  return v;
-}
-__device__ __forceinline__ uint32_t ctl_add(uint32_t* p, uint32_t value, uint32_t after) {
-  uint32_t v;
-  asm("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0) ; after %3" : "=&v"(v) : "v"(p), "v"(value), "v"(after));
-  return v;
-}
-__device__ __forceinline__ uint32_t ctl_store(uint32_t* p, uint32_t value) {  // -> value
-  uint32_t v;
-  asm("global_store_dword %1, %2, off sc1\n\tv_mov_b32 %0, %2" : "=&v"(v) : "v"(p), "v"(value));
-  return v;
-}
-__device__ __forceinline__ long long claim_unit(uint32_t* ctl, long long index) {
-#if RM_DYN_KO == 1
-  return index;
-#endif
-  uint32_t* const slot = ctl + 32 + index;
-  uint32_t turn = 0u;
-  uint32_t v = __builtin_amdgcn_readfirstlane(ctl_load(slot, turn));
-#if RM_DYN_KO != 3 && RM_DYN_KO != 4
-  if (v == 0u) {
-    uint32_t r = 0u;
-    if ((threadIdx.x & 63) == 0) {
-      r = ctl_cas(slot, 0u, 1u);
-      if (r == 0u) r = ctl_store(slot, ctl_add(ctl, 1u, r) + 2u);
-    }
-    v = __builtin_amdgcn_readfirstlane(r);
-  }
-#endif
-#if RM_DYN_KO != 2 && RM_DYN_KO != 4
-  while (v == 1u) {
-    v = __builtin_amdgcn_readfirstlane(ctl_load_later(slot, ++turn));
-  }
-#endif
-  return (long long)v - 2;
-}
-
 template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH>
-__device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds, unsigned& claim_info) {
+__device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
   using M = typename rmk::ArithOf<ARITH>::type;
   using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
   const int pp_log2 = a.pp_log2;
@@ -278,24 +191,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
       // whole rows; units of 1 or 3 rows: slower.
       const long long nsu = a.xcd2d, sw = a.bpr / (8 * nsu), per_unit = 2 * sw, pairs = a.rows_real >> 1;
       const long long ul = m / per_unit, rp = ul / nsu, jj = ul - rp * nsu;
-      if (a.dyn) {
-        // UNITS DEALT AT RUN TIME: the launch holds an eighth more groups of wavefronts per XCD than units, and a group
-        // renders the unit it claims -- an XCD whose units were cheap renders more of them (those of the bottom rows first,
-        // left to right); groups that find the units gone leave.  (An odd last row is the top half of a unit of its own.)
-#ifdef RM_XCD_CLOCK
-        const unsigned long long c0 = xcd_clock_now((unsigned)ul);
-        const long long g = claim_unit(a.dyn, k * a.dyn_slots + ul);
-        const unsigned long long c1 = xcd_clock_now((unsigned)g);
-        claim_info = ((unsigned)(c1 - c0) << 1) | (g >= a.dyn_units ? 1u : 0u);  // (diagnostic: ticks in claim_unit, no unit found)
-#else
-        const long long g = claim_unit(a.dyn, k * a.dyn_slots + ul);
-#endif
-        if (g >= a.dyn_units) return;
-        const long long w = m - ul * per_unit, chunk = w >> pp_log2, grp = g / (8 * nsu);
-        row = 2 * grp + (chunk & 1);
-        if (row >= a.rows_real) return;
-        col = (g - grp * 8 * nsu) * sw + ((chunk >> 1) << pp_log2) + (w & (pp - 1));
-      } else if (rp < pairs) {
+      if (rp < pairs) {
         const long long w = m - ul * per_unit, chunk = w >> pp_log2;
         row = 2 * rp + (chunk & 1);
         col = (((k - rp) & 7) + 8 * jj) * sw + ((chunk >> 1) << pp_log2) + (w & (pp - 1));
@@ -393,6 +289,31 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   }
 }
 
+#ifdef RM_XCD_CLOCK
+// DIAGNOSTIC BUILD ONLY (tools/ab_build.py clock=-DRM_XCD_CLOCK, tools/xcd_clock.py): when each XCD started and finished its share
+// of the frame kernel's launches, on the 100 MHz constant clock.  [x]: first start, [16 + x]: last end, [32 + x]: sum of the
+// wavefronts' lifetimes, [48 + x]: wavefronts (low 32 bits) and those whose block index mod 8 is NOT x (high 32 bits).
+__device__ unsigned long long g_xcd_clock[64];
+// (the first reading as asm that is neither volatile nor clobbers memory: behind wall_clock64() -- or any atomic, volatile asm
+//  or store -- the compiler's pass that marks loads as not clobbered gives up, the 800 uniform loads of the kernel (the render
+//  options) become vector loads and the allocator answers with 100 spilled VGPRs instead of 23: the first version of this
+//  diagnostic ran 47 % slower than the product, this one 4 %)
+__device__ __forceinline__ unsigned long long xcd_clock_now(unsigned after) {
+  unsigned long long t;
+  asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0) ; after %1" : "=s"(t) : "s"(after));
+  return t;
+}
+__device__ __forceinline__ void xcd_clock_note(unsigned long long t0) {
+  const unsigned long long t1 = wall_clock64();
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned x = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
+    atomicMin(&g_xcd_clock[x], t0);
+    atomicMax(&g_xcd_clock[16 + x], t1);
+    atomicAdd(&g_xcd_clock[32 + x], t1 - t0);
+    atomicAdd(&g_xcd_clock[48 + x], (blockIdx.x & 7) == x ? 1ull : (1ull << 32) + 1ull);
+  }
+}
+#endif
 
 template <bool ACCEL, int MINW, bool SDFM, int LAYOUT = 0, int ARITH = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel(const FrameArgs a) {
@@ -400,16 +321,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, MINW) void render_frame_kernel
   __shared__ float wave_lds[(ACCEL || (SDFM && RM_SDF_WAVE)) ? rmk::Tracer<false, ACCEL, SDFM>::kWaveLdsFloats : 3 * 64];
 #ifdef RM_XCD_CLOCK
   const unsigned long long t0 = xcd_clock_now(blockIdx.x);
-#endif
-#ifdef RM_XCD_CLOCK
-  unsigned claim_info = 0u;
-  frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x + (t0 == ~0ull ? 1 : 0), wave_lds, claim_info);  // (pins the first reading to the start)
+  frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x + (t0 == ~0ull ? 1 : 0), wave_lds);  // (pins the first reading to the start)
+  xcd_clock_note(t0);
 #else
-  unsigned claim_info = 0u;
-  frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x, wave_lds, claim_info);
-#endif
-#ifdef RM_XCD_CLOCK
-  xcd_clock_note(t0, claim_info);
+  frame_block<ACCEL, SDFM, LAYOUT, ARITH>(a, blockIdx.x, wave_lds);
 #endif
 }
 
@@ -641,7 +556,7 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
     const long long groups = rows / 8, tail_blocks = (rows % 8) * bpr, share = (tail_blocks + 7) / 8;
     blocks = groups * 8 * bpr + 8 * share;
     if (bpr_out) *bpr_out = bpr;
-    if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; rows_out[3] = 0; rows_out[4] = rows_out[5] = 0; }
+    if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; rows_out[3] = 0; }
     // 2-D units: stripes must hold whole tiles.  Unit width 1/(8 nsu) of a row; auto (xcd_2d < 0): the narrowest unit that
     // still holds at least half of the wavefronts an XCD has in flight (7 per SIMD x 4 x 32 CUs = 896) -- measured: config 2
     // (640 wavefronts per unit at nsu = 1, 320 at 2) is fastest at 1, config 3 (960 / 480) at 2 (-4.6 % against 1), config 4
@@ -659,12 +574,6 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
       if (nsu > 0 && tpr % (8 * nsu) == 0) {
         blocks = rows * bpr;
         if (rows_out) rows_out[3] = nsu;
-        // units dealt at run time: an eighth more groups per XCD than its share of the units (frame_block)
-        const long long units = ((rows + 1) / 2) * 8 * nsu, per_xcd = (units / 8) + (units / 8 + 7) / 8 + 1;
-        if (f.dyn_ctl && rows_out && (size_t)(32 + 8 * per_xcd) * sizeof(uint32_t) <= f.dyn_ctl_bytes && units < (1ll << 30)) {
-          blocks = 8 * per_xcd * 2 * (bpr / (8 * nsu));
-          rows_out[4] = (int)units; rows_out[5] = (int)per_xcd;
-        }
       }
     }
   }
@@ -676,17 +585,11 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
   const int tpp = tiles_per_part(g.tiles_total, tile_stride);
   int bpr = 0, pp_log2 = 0;
-  int rows3[6] = {0, 0, 0, 0, 0, 0};
+  int rows3[4] = {0, 0, 0, 0};
   const long long blocks = frame_grid(f, &bpr, &pp_log2, rows3);
   if (blocks == 0) return hipSuccess;
   FrameArgs a;
   a.rows_real = rows3[0]; a.full_groups = rows3[1]; a.tail_share = rows3[2]; a.xcd2d = rows3[3];
-  a.dyn = nullptr; a.dyn_units = rows3[4]; a.dyn_slots = rows3[5];
-  if (rows3[4] > 0) {
-    a.dyn = f.dyn_ctl;
-    const hipError_t e = hipMemsetAsync(a.dyn, 0, (size_t)(32 + 8 * rows3[5]) * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-  }
   a.vox = f.vox;
   a.dist8 = f.accel.dist;
   a.surf32 = f.accel.surf;
@@ -779,10 +682,10 @@ hipError_t launch_prims(hipStream_t st, int op, const float* a, const float* b, 
 #ifdef RM_XCD_CLOCK
 extern "C" int rm_debug_xcd_clock(unsigned long long* out64, int reset) {
   hipError_t e = hipDeviceSynchronize();
-  if (e == hipSuccess && out64) e = hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_xcd_clock), 96 * sizeof(unsigned long long));
+  if (e == hipSuccess && out64) e = hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_xcd_clock), 64 * sizeof(unsigned long long));
   if (e == hipSuccess && reset) {
-    unsigned long long init[96];
-    for (int i = 0; i < 96; ++i) init[i] = i < 16 ? ~0ull : 0ull;
+    unsigned long long init[64];
+    for (int i = 0; i < 64; ++i) init[i] = i < 16 ? ~0ull : 0ull;
     e = hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_clock), init, sizeof(init));
   }
   return (int)e;

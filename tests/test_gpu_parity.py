@@ -356,9 +356,8 @@ def test_frame_is_independent_of_the_xcd_unit_width(native, monkeypatch, w, h, s
     frames = {}
     for key, env in (("plain", {"RAYMARCH_XCD_ROWS": "0"}), ("auto", {}), ("0", {"RAYMARCH_XCD_2D": "0"}), ("1", {"RAYMARCH_XCD_2D": "1"}),
                      ("2", {"RAYMARCH_XCD_2D": "2"}), ("4", {"RAYMARCH_XCD_2D": "4"}), ("8", {"RAYMARCH_XCD_2D": "8"}),
-                     ("2asc", {"RAYMARCH_XCD_2D": "2", "RAYMARCH_ROW_ORDER": "asc"}), ("dealt", {"RAYMARCH_XCD_DYN": "1"}),
-                     ("dealt2", {"RAYMARCH_XCD_DYN": "1", "RAYMARCH_XCD_2D": "2"}), ("fixed", {"RAYMARCH_XCD_DYN": "0"})):
-        for k in ("RAYMARCH_XCD_ROWS", "RAYMARCH_XCD_2D", "RAYMARCH_ROW_ORDER", "RAYMARCH_XCD_DYN"):
+                     ("2asc", {"RAYMARCH_XCD_2D": "2", "RAYMARCH_ROW_ORDER": "asc"})):
+        for k in ("RAYMARCH_XCD_ROWS", "RAYMARCH_XCD_2D", "RAYMARCH_ROW_ORDER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

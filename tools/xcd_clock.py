@@ -42,7 +42,7 @@ def main():
     for _ in range(4):
         fr.render()
         torch.cuda.synchronize(dev)
-    buf = np.zeros(96, np.uint64)
+    buf = np.zeros(64, np.uint64)
     print(f"{args.workload}: {wl['desc']}   (times in us from the first wavefront's start; one blocking frame each)")
     for f in range(args.frames):
         assert fn(None, 1) == 0
@@ -61,11 +61,6 @@ def main():
         print("   first start us : " + " ".join(f"{v:8.1f}" for v in start))
         print("   last end us    : " + " ".join(f"{v:8.1f}" for v in end) + f"   spread {end.max() - end.min():.1f} us = {100 * (end.max() - end.min()) / end.max():.2f} % of the frame")
         print("   lifetimes, ms  : " + " ".join(f"{v / 1000:8.1f}" for v in life) + f"   max/mean {life.max() / life.mean():.4f}")
-        claim = np.array([int(buf[64 + i]) / 100.0 for i in x])
-        empty = np.array([int(buf[80 + i]) for i in x])
-        if claim.sum() > 0:
-            print("   claim, us/wave : " + " ".join(f"{c / w:8.2f}" for c, w in zip(claim, waves)) + f"   ({100 * claim.sum() / life.sum():.2f} % of the lifetimes)")
-            print("   rendering waves: " + " ".join(f"{w - e:8d}" for w, e in zip(waves, empty)))
         print("   mean in flight : " + " ".join(f"{l / (e - s):8.1f}" for l, e, s in zip(life, end, start)))
 
 
