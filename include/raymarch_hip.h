@@ -358,6 +358,17 @@ int rm_debug_get_octants(rm_ctx* ctx, int iso, uint8_t* oct_out);
  * The default order is plain bottom to top.  Pixels never depend on it.  Host-side, no device needed. */
 int rm_debug_volume_band(const void* opts, double* lo, double* hi);
 
+/* Test hook: the dispatch order of ONE launch of the frame kernel (rm_kernels.hip logical_block, the function the kernel
+ * compiles, evaluated on the host).  An image of n pixels in rows of resx, `passes` (1..64) passes in the launch, the
+ * tiles tile_first, tile_first + tile_stride, ... of it (rm_frame_device's partition; 0, 1 = all).  xcd_rows / xcd_2d /
+ * rows_desc / band_lo, band_hi: the switches RAYMARCH_XCD_ROWS, RAYMARCH_XCD_2D (-1 = chosen per launch), RAYMARCH_ROW_ORDER,
+ * RAYMARCH_ROW_BAND set.  out[b] (b < cap) = tile << 8 | sub-block of the tile that hardware workgroup b renders, or -1
+ * for a workgroup that leaves at once.  -> workgroups of the launch (the grid), or a negative error code.  Every
+ * (tile, sub-block) of the partition appears exactly once: the order is a permutation (tests/test_host_abi.py).
+ * Host-side, no device needed. */
+long long rm_debug_block_order(int resx, int n, int passes, int tile_first, int tile_stride, int xcd_rows, int xcd_2d,
+                               int rows_desc, double band_lo, double band_hi, long long* out, long long cap);
+
 /* ---- host-side parameter layer (no device needed) ------------------------
  * The reference builds its inputs in Clojure; a non-Python host gets the same
  * helpers here.  NaN in a double field of rm_render_args means "not given"

@@ -68,7 +68,7 @@ EXPORTS = [
     "rm_render_image", "rm_render_image_range", "rm_render_image_counted", "rm_tonemap_image",
     "rm_render_frame", "rm_set_sdf_volume", "rm_render_sdf_frame", "rm_tiles_per_part", "rm_frame_device", "rm_resolve_device",
     "rm_frame_device_argb", "rm_resolve_device_argb", "rm_last_frame_breakdown",
-    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_debug_volume_band", "rm_selftest_prims", "rm_selftest_filter",
+    "rm_check_device_opts", "rm_last_frame_timing", "rm_frame_timing_history", "rm_debug_get_accel", "rm_debug_get_octants", "rm_debug_volume_band", "rm_debug_block_order", "rm_selftest_prims", "rm_selftest_filter",
     "rm_render_options", "rm_compute_eyepos", "rm_make_scatter_table", "rm_make_gyroid_host",
     "rm_vox_save", "rm_vox_info", "rm_vox_load",
 ]
@@ -84,6 +84,19 @@ def volume_band(opts_record):
     lo, hi = ctypes.c_double(), ctypes.c_double()
     check(lib().rm_debug_volume_band(bytes(opts_record[:OPTS_BYTES]), ctypes.byref(lo), ctypes.byref(hi)))
     return float(lo.value), float(hi.value)
+
+
+def block_order(resx, n, passes, tile_first=0, tile_stride=1, xcd_rows=True, xcd_2d=-1, rows_desc=True, band=(0.0, 0.0)):
+    """-> int64 array, one entry per hardware workgroup of that frame-kernel launch: tile << 8 | sub-block, or -1 for a
+    workgroup that leaves at once (rm_debug_block_order).  Host-side."""
+    args = (int(resx), int(n), int(passes), int(tile_first), int(tile_stride), int(bool(xcd_rows)), int(xcd_2d), int(bool(rows_desc)),
+            float(band[0]), float(band[1]))
+    blocks = lib().rm_debug_block_order(*args, None, 0)
+    if blocks < 0:
+        check(int(blocks))
+    out = np.empty(blocks, np.int64)
+    lib().rm_debug_block_order(*args, out.ctypes.data, blocks)
+    return out
 
 
 class RmError(RuntimeError):
@@ -244,6 +257,8 @@ def lib():
     L.rm_debug_get_accel.argtypes = [_vp, _i, _vp, _vp]
     L.rm_debug_get_octants.argtypes = [_vp, _i, _vp]
     L.rm_debug_volume_band.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.rm_debug_block_order.restype = ctypes.c_longlong
+    L.rm_debug_block_order.argtypes = [_i] * 8 + [ctypes.c_double, ctypes.c_double, _vp, ctypes.c_longlong]
     _lib = L
     return L
 

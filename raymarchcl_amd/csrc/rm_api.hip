@@ -1524,6 +1524,19 @@ int rm_debug_volume_band(const void* opts, double* lo, double* hi) {
   return RM_OK;
 }
 
+long long rm_debug_block_order(int resx, int n, int passes, int tile_first, int tile_stride, int xcd_rows, int xcd_2d, int rows_desc,
+                               double band_lo, double band_hi, long long* out, long long cap) {
+  if (resx <= 0 || n <= 0 || passes <= 0 || passes > 64 || tile_stride < 1 || tile_first < 0 || (cap > 0 && !out))
+    return fail(RM_EINVAL, "bad argument");
+  rmk::FrameLaunch f;
+  f.resx = resx; f.n = n; f.passes = passes; f.tile_first = tile_first; f.tile_stride = tile_stride;
+  f.pp_log2 = 0;
+  while ((1 << f.pp_log2) < passes) f.pp_log2++;  // (one launch = what one wavefront holds)
+  f.xcd_rows = xcd_rows != 0; f.xcd_2d = xcd_2d; f.rows_desc = rows_desc != 0;
+  f.band_lo = band_lo; f.band_hi = band_hi;
+  return rmk::debug_block_order(f, out, cap);
+}
+
 int rm_debug_get_octants(rm_ctx* c, int iso, uint8_t* oct_out) {
   int rc = check_ctx(c);
   if (rc) return rc;

@@ -55,6 +55,8 @@ struct FrameLaunch {
   int arith = 0;
 };
 hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f);
+// host arithmetic: out[b] = tile << 8 | sub-block that hardware block b of that launch renders, -1 = padding; -> blocks of the grid
+long long debug_block_order(const FrameLaunch& f, long long* out, long long cap);
 // true: the frame kernel of this volume's table layout takes records with any number of AO probes (chunked exchange)
 bool frame_takes_any_ao(const Accel& accel);
 

@@ -152,20 +152,11 @@ __device__ __forceinline__ uint32_t tonemap_argb(float px, float py, float pz, f
   return 0xff000000u | (ch[0] << 16) | (ch[1] << 8) | ch[2];
 }
 
-// A launch holds at most the passes ONE wavefront holds (2^pp_log2): frames with more passes go out as several
-// launches that continue each other's accumulator (rm_api.hip frame_on_device) -- nothing of a sample then lives
-// across the body of another, and the kernel has no loop over groups of passes.
-// ARITH: the arithmetic contract, rmk::ArithOf (rm_math.hpp): 0 = OpenCL CPU device arithmetic and casts, 1 = the same
-// with the GPU lowering of the seed casts, 2 / 3 = ROCm's OpenCL library on this GPU, strict / default reference build
-template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH>
-__device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
-  using M = typename rmk::ArithOf<ARITH>::type;
-  using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
-  const int pp_log2 = a.pp_log2;
-  const int pp = 1 << pp_log2;              // passes per wavefront
-  const int ppw = 64 >> pp_log2;            // pixels per wavefront
-  const TileGeom g = tile_geom(a.resx, a.n);
-  const int lane = threadIdx.x & 63;
+// hardware block -> logical block of the launch (tile slot << pp_log2 | sub-block), or -1 for the padding of the XCD-aware
+// grid.  A permutation: every logical block of the launch is rendered by exactly one hardware block, whatever the order
+// (tests/test_host_abi.py walks it on the host through rm_debug_block_order for many image shapes, partitions and orders).
+template <class Args>
+__host__ __device__ __forceinline__ long long logical_block(const Args& a, long long hw_block) {
   // XCD-aware order (bpr > 0): the dispatcher deals consecutive workgroups to the 8
   // XCDs round-robin, each with its own L2.  Hardware block b = 8*m + k is given the
   // logical block of tile row 8*(m / bpr) + k, so XCD k renders every 8th tile ROW:
@@ -173,6 +164,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
   // while rows stay interleaved finely enough to balance the load.
   long long lb = hw_block;
   if (a.bpr > 0) {
+    const int pp_log2 = a.pp_log2, pp = 1 << pp_log2;
     const long long m = lb >> 3, k = lb & 7;
     // The dispatcher's assignment of workgroups to XCDs is STATIC (workgroup i -> XCD i % 8), so an XCD's share of the
     // frame is fixed by this mapping.  Whole groups of 8 tile rows give every XCD one row each.  The last r < 8 rows used to
@@ -197,7 +189,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
         col = (((k - rp) & 7) + 8 * jj) * sw + ((chunk >> 1) << pp_log2) + (w & (pp - 1));
       } else {
         const long long w = m - pairs * nsu * per_unit;  // an odd last row: 1/8 of it per XCD
-        if (w >= sw * nsu || !(a.rows_real & 1)) return;
+        if (w >= sw * nsu || !(a.rows_real & 1)) return -1;
         row = a.rows_real - 1;
         col = ((k - rp) & 7) * (sw * nsu) + w;
       }
@@ -206,7 +198,7 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
       col = m % a.bpr;
     } else {
       const long long j = k * (long long)a.tail_share + (m - full);
-      if (m - full >= a.tail_share || j >= (long long)(a.rows_real - 8 * a.full_groups) * a.bpr) return;  // (padding of the shares)
+      if (m - full >= a.tail_share || j >= (long long)(a.rows_real - 8 * a.full_groups) * a.bpr) return -1;  // (padding of the shares)
       row = 8ll * a.full_groups + j / a.bpr;
       col = j % a.bpr;
     }
@@ -224,6 +216,25 @@ __device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_blo
     }
     lb = at_row * a.bpr + col;
   }
+  return lb;
+}
+
+// A launch holds at most the passes ONE wavefront holds (2^pp_log2): frames with more passes go out as several
+// launches that continue each other's accumulator (rm_api.hip frame_on_device) -- nothing of a sample then lives
+// across the body of another, and the kernel has no loop over groups of passes.
+// ARITH: the arithmetic contract, rmk::ArithOf (rm_math.hpp): 0 = OpenCL CPU device arithmetic and casts, 1 = the same
+// with the GPU lowering of the seed casts, 2 / 3 = ROCm's OpenCL library on this GPU, strict / default reference build
+template <bool ACCEL, bool SDFM, int LAYOUT, int ARITH>
+__device__ __forceinline__ void frame_block(const FrameArgs& a, long long hw_block, float* wave_lds) {
+  using M = typename rmk::ArithOf<ARITH>::type;
+  using Tr = rmk::Tracer<false, ACCEL, SDFM, LAYOUT, M>;
+  const int pp_log2 = a.pp_log2;
+  const int pp = 1 << pp_log2;              // passes per wavefront
+  const int ppw = 64 >> pp_log2;            // pixels per wavefront
+  const TileGeom g = tile_geom(a.resx, a.n);
+  const int lane = threadIdx.x & 63;
+  const long long lb = logical_block(a, hw_block);
+  if (lb < 0) return;
   // wavefronts of a tile are consecutive: tile slot = w / pp, sub-block = w % pp
   const long long slot = lb >> pp_log2;
   const int sub = (int)(lb & (pp - 1));
@@ -580,16 +591,50 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
   return blocks;
 }
 
-hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
+// the part of a launch's arguments that decides which hardware block renders what (logical_block); -> blocks of the grid
+static long long frame_order_args(const FrameLaunch& f, FrameArgs& a) {
   const TileGeom g = tile_geom(f.resx, f.n);
   const int tile_stride = f.tile_stride < 1 ? 1 : f.tile_stride;
-  const int tpp = tiles_per_part(g.tiles_total, tile_stride);
   int bpr = 0, pp_log2 = 0;
   int rows3[4] = {0, 0, 0, 0};
   const long long blocks = frame_grid(f, &bpr, &pp_log2, rows3);
-  if (blocks == 0) return hipSuccess;
-  FrameArgs a;
   a.rows_real = rows3[0]; a.full_groups = rows3[1]; a.tail_share = rows3[2]; a.xcd2d = rows3[3];
+  a.n = f.n; a.resx = f.resx; a.tile_first = f.tile_first; a.tile_stride = tile_stride;
+  a.tiles_per_part = tiles_per_part(g.tiles_total, tile_stride); a.pp_log2 = pp_log2; a.passes = f.passes; a.bpr = bpr;
+  a.rows_desc = f.rows_desc ? 1 : 0;
+  a.band_r0 = a.band_r1 = 0;
+  if (bpr > 0 && f.rows_desc && f.band_hi > f.band_lo) {  // image-height fractions -> rows of this launch's grid
+    const long long rows_real = a.rows_real;
+    long long r0 = (long long)(f.band_lo * (double)rows_real), r1 = (long long)(f.band_hi * (double)rows_real) + 1;
+    r0 = r0 < 0 ? 0 : r0;
+    r1 = r1 > rows_real ? rows_real : r1;
+    if (r1 > r0) { a.band_r0 = (int)r0; a.band_r1 = (int)r1; }
+  }
+  return blocks;
+}
+
+// rm_debug_block_order: what every hardware block of that launch would render -- out[b] = tile << 8 | sub-block, or -1 for a
+// block that leaves at once (padding).  Host arithmetic only: the same logical_block() the kernel compiles.
+long long debug_block_order(const FrameLaunch& f, long long* out, long long cap) {
+  FrameArgs a{};
+  const long long blocks = frame_order_args(f, a);
+  const TileGeom g = tile_geom(f.resx, f.n);
+  for (long long b = 0; b < blocks && b < cap; ++b) {
+    const long long lb = logical_block(a, b);
+    out[b] = -1;
+    if (lb < 0) continue;
+    const long long slot = lb >> a.pp_log2, tile = a.tile_first + slot * a.tile_stride;
+    if (slot >= a.tiles_per_part || tile >= g.tiles_total) continue;
+    out[b] = (tile << 8) | (lb & ((1 << a.pp_log2) - 1));
+  }
+  return blocks;
+}
+
+hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
+  FrameArgs a;
+  const long long blocks = frame_order_args(f, a);
+  if (blocks == 0) return hipSuccess;
+  const int pp_log2 = a.pp_log2;
   a.vox = f.vox;
   a.dist8 = f.accel.dist;
   a.surf32 = f.accel.surf;
@@ -600,18 +645,7 @@ hipError_t launch_render_frame(hipStream_t st, const FrameLaunch& f) {
   a.opts0 = f.opts0;
   a.acc = reinterpret_cast<float4*>(f.acc);
   a.argb = f.argb;
-  a.n = f.n; a.resx = f.resx; a.tile_first = f.tile_first; a.tile_stride = tile_stride;
-  a.tiles_per_part = tpp; a.pp_log2 = pp_log2; a.passes = f.passes; a.bpr = bpr;
   a.accumulate = f.accumulate ? 1 : 0;
-  a.rows_desc = f.rows_desc ? 1 : 0;
-  a.band_r0 = a.band_r1 = 0;
-  if (bpr > 0 && f.rows_desc && f.band_hi > f.band_lo) {  // image-height fractions -> rows of this launch's grid
-    const long long rows_real = a.rows_real;
-    long long r0 = (long long)(f.band_lo * (double)rows_real), r1 = (long long)(f.band_hi * (double)rows_real) + 1;
-    r0 = r0 < 0 ? 0 : r0;
-    r1 = r1 > rows_real ? rows_real : r1;
-    if (r1 > r0) { a.band_r0 = (int)r0; a.band_r1 = (int)r1; }
-  }
   a.row_major = f.row_major ? 1 : 0;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   if (f.passes > (1 << pp_log2)) return hipErrorInvalidValue;  // (the caller splits a run into such launches)

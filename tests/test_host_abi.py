@@ -139,3 +139,58 @@ def test_volume_band_is_the_rows_where_the_clip_box_covers_most(native):
     for cfg_w, cfg_h in ((1280, 720), (1920, 1080), (3840, 2160)):  # BASELINE's camera: the box fills the view, plain order
         o = rm.render_options(width=cfg_w, height=cfg_h, vres=[256] * 3, iter=16, mat="orange-stripes", **cases[0])
         assert native.volume_band(structs.encode_bytes(o)) == (0.0, 0.0)
+
+
+def _check_block_order(native, w, h, passes, first, stride, **kw):
+    """every (tile, sub-block) of the partition exactly once; -> (hardware blocks, padding blocks)"""
+    n = w * h
+    order = native.block_order(w, n, passes, tile_first=first, tile_stride=stride, **kw)
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    tiles_total = tiles_x * tiles_y
+    pp = 1
+    while pp < passes:
+        pp *= 2
+    mine = np.arange(first, tiles_total, stride, dtype=np.int64)
+    want = np.sort(((mine[:, None] << 8) | np.arange(pp, dtype=np.int64)[None, :]).ravel())
+    got = np.sort(order[order >= 0])
+    assert np.array_equal(got, want), (w, h, passes, first, stride, kw, got.size, want.size)
+    return order.size, int((order < 0).sum())
+
+
+def test_dispatch_order_of_the_frame_kernel_is_a_permutation(native):
+    """rm_debug_block_order = the kernel's own block mapping (rm_kernels.hip logical_block) evaluated on the host: whatever
+    the order -- plain, whole tile rows per XCD with the last rows in equal shares, 2-D units of every width, bottom to
+    top, a band of rows first -- every sub-block of every tile of the launch's partition is rendered by exactly one
+    hardware workgroup.  BASELINE's five image sizes, odd and tiny images, widths whose rows hold 8 / 16 / 32 / 64 tiles or
+    none of them, 1..32 passes per wavefront, the tile partitions of 2 / 4 / 8 ranks."""
+    shapes = [(1280, 720), (256, 256), (1920, 1080), (3840, 2160), (1280, 88), (1024, 40), (768, 24), (512, 8), (64, 64),
+              (1283, 77), (17, 9), (8, 8), (2048, 16), (640, 360), (1280, 8)]
+    checked = 0
+    for w, h in shapes:
+        big = w * h > 3_000_000
+        for passes in ((16,) if big else (1, 2, 3, 16, 25, 32)):
+            for stride in ((1, 8) if big else (1, 2, 4, 8)):
+                for first in sorted({0, stride - 1}):
+                    for kw in (dict(xcd_rows=False), dict(xcd_2d=0), dict(xcd_2d=0, rows_desc=False), dict(), dict(xcd_2d=1),
+                               dict(xcd_2d=2), dict(xcd_2d=4), dict(xcd_2d=8, rows_desc=False), dict(band=(0.33, 0.83)),
+                               dict(xcd_2d=0, band=(0.0, 0.5))):
+                        if big and kw.get("xcd_2d", -1) in (1, 8):
+                            continue
+                        blocks, padding = _check_block_order(native, w, h, passes, first, stride, **kw)
+                        checked += 1
+                        # the padding of the XCD-aware grid stays small next to a real frame
+                        if w * h >= 640 * 360 and stride == 1:
+                            assert padding <= 0.02 * blocks, (w, h, passes, kw, blocks, padding)
+    assert checked > 1500
+    # the 2-D units need no padding at all where they apply, and the launcher's own choice of the width applies to BASELINE's sizes
+    for w, h in ((1280, 720), (1920, 1080), (3840, 2160)):
+        order = native.block_order(w, w * h, 16)
+        assert (order >= 0).all() and order.size == (w // 8) * ((h + 7) // 8) * 16
+
+
+def test_block_order_rejects_bad_arguments(native):
+    for args in ((0, 64, 1), (64, 0, 1), (64, 64, 0), (64, 64, 65)):
+        with pytest.raises(native.RmError):
+            native.block_order(*args)
+    with pytest.raises(native.RmError):
+        native.block_order(64, 64, 1, tile_stride=0)
