@@ -94,16 +94,20 @@ class Checker:
         assert str(z["inputs"]) == input_digest(vox, opts, mc, n), f"fixture {key} was recorded for other inputs"
         return z["pixels"].copy(), z["argb"].copy()
 
-    def assert_frame(self, key, vox, opts, mc, n, px, argb):
+    def assert_frame(self, key, vox, opts, mc, n, px, argb, undefined=None):
         """The product's (px, argb) equal the reference build's, bit for bit.  Full comparison
-        when the reference is live or the fixture holds the frame; digest + sample otherwise."""
+        when the reference is live or the fixture holds the frame; digest + sample otherwise.
+        `undefined`: mask of the work-items whose value the REFERENCE leaves undefined (undefined_work_items below) --
+        a live build returns whatever its scratch memory held there, so they are left out of the full comparison."""
         px = np.asarray(px, dtype=np.float32).reshape(-1)
         if self.live or os.path.exists(os.path.join(self.fixed, key + ".npz")):
             want, want_argb = self.frame(key, vox, opts, mc, n)
-            bad = int((px.view(np.uint32) != want.view(np.uint32)).reshape(-1, 4).any(axis=1).sum())
+            keep = np.ones(n, bool) if undefined is None else ~np.asarray(undefined, bool)
+            differs = (px.view(np.uint32) != want.view(np.uint32)).reshape(-1, 4).any(axis=1)
+            bad = int((differs & keep).sum())
             assert bad == 0, f"{key}: {bad} pixels differ from the reference build ({self.source()})"
             if argb is not None:
-                assert np.array_equal(argb, want_argb), key
+                assert np.array_equal(np.asarray(argb)[keep], want_argb[keep]), key
             return
         d = self._digests().get(key)
         if d is None:
@@ -117,6 +121,20 @@ class Checker:
         assert sha(px) == d["pixels_sha"], f"{key}: accumulator digest differs from the reference build's"
         if argb is not None:
             assert sha(np.asarray(argb, dtype=np.uint32)) == d["argb_sha"], f"{key}: ARGB digest differs"
+
+
+def undefined_work_items(oracle, vox, opts, mc, n):
+    """-> bool[n]: the work-items whose material index leaves the record in some pass.  The reference reads its PRIVATE
+    copy of the record out of bounds there (renderer.cl:394,418): undefined behaviour -- a build of it returns what its
+    scratch memory happened to hold (zeros on a fresh device, which is the value the product defines; anything, NaN
+    included, after other kernels have run: seen once in round 6 on pixel 31669 of config 1, its only such work-item).
+    Found by the CPU restatement, which marks them; seconds for config 1, too slow for the big configurations (none of
+    which has one: profiles/r06_pin_gfx950.txt for config 2; configs 3-5 by their digests holding across boxes)."""
+    mask = np.zeros(n, np.uint8)
+    scratch = np.zeros(4 * n, np.float32)
+    for i in range(len(opts) // 544):
+        oracle.render_image(vox, mc[i], opts[i * 544:(i + 1) * 544], scratch, n=n, undefined_mask=mask)
+    return mask != 0
 
 
 def rel_err(a, b):

@@ -3,7 +3,7 @@ gfx950, else its committed recordings under tests/golden/gfx950_<build>/; with n
 import pytest
 
 from oracle.pin import (BUILDS, CONTRACT_OF, METRIC_BUILD, RECORDED, SAMPLE_STRIDE, Checker, CheckerMissing,  # noqa: F401
-                        FastReference, fixed_dir, input_digest, rel_err, sha)
+                        FastReference, fixed_dir, input_digest, rel_err, sha, undefined_work_items)
 
 FIXED = fixed_dir("strict")
 

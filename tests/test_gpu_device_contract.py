@@ -88,7 +88,7 @@ def test_pass_packed_wavefronts(native, pin_each, monkeypatch, passes, pack):
 
 
 @pytest.mark.parametrize("config", ["c1", "c2", "c3", "c4", "c5"])
-def test_baseline_configurations_whole_frames(native, pin_each, config):
+def test_baseline_configurations_whole_frames(native, pin_each, config, oracle_mod):
     """Every BASELINE configuration at its full size, the WHOLE frame: the reference kernel renders
     it on this GPU (C2: 16 launches, ~0.25 s; C4: 64 launches over 8.3 M pixels; or its recorded
     output is read: all of config 1, digest + every 997th pixel of configs 2-5), the product renders
@@ -105,7 +105,12 @@ def test_baseline_configurations_whole_frames(native, pin_each, config):
         px, argb = ctx.render_frame(opts, mc, n)
         ms, launches = ctx.last_frame_timing()
     print(f"{config} ({contract}): {n} pixels x {wl['spp']} passes -- this path {ms:.2f} ms, checker: {pin.source()}")
-    pin.assert_frame(config, vox, opts, mc, n, px, argb)
+    # (config 1 holds ONE work-item the reference leaves undefined: a live build returns scratch residue there)
+    import gfx950_pin as gp
+
+    undefined = gp.undefined_work_items(oracle_mod, vox, opts, mc, n) if config == "c1" else None
+    assert undefined is None or int(undefined.sum()) == 1
+    pin.assert_frame(config, vox, opts, mc, n, px, argb, undefined=undefined)
     assert len(np.unique(px.reshape(-1, 4)[::97, :3])) > 1000  # a real image
 
 

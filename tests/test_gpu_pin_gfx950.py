@@ -157,7 +157,8 @@ def test_every_config_full_size_against_the_references_own_build(config, native,
     r = gp.rel_err(got.reshape(-1, 4)[::stride], want)
     frac = _report(config, r, stride, fast_ref.source())
     assert frac >= FLOOR[config], (config, frac)
-    pin_default.assert_frame(config, vox, opts, mc, n, got, None)  # ... and it IS the `default` build, bit for bit
+    undefined = gp.undefined_work_items(oracle_mod, vox, opts, mc, n) if config == "c1" else None  # (one work-item, oracle/pin.py)
+    pin_default.assert_frame(config, vox, opts, mc, n, got, None, undefined=undefined)  # ... and it IS the `default` build, bit for bit
     if fast_ref.live and config in ("c1", "c2"):  # (the strict build of the big frames: seconds of GPU time each, shown in the profile)
         strict = oracle_mod.gfx950_render_frame(vox, opts, mc, n, build="strict", tonemap=False)[0]
         frac_strict = float((gp.rel_err(strict, want) <= 1e-4).mean())
