@@ -113,6 +113,8 @@ struct rm_ctx {
                              // 136.0 / 137.3 / 140.3 ms) ...
   bool pass_pack_auto = true;  // ... except that a run of 20..31 passes goes out as ONE launch of 2 pixels x 32 slots instead of
                              // 16 + a partial group (25 passes: config 5 -2.7 %); off when RAYMARCH_PASS_PACK is given
+  int cus = 256;             // compute units of the device (thin launches below)
+  bool thin_wide = true;     // RAYMARCH_THIN=0: no widening of thin launches (A/B)
   int pack_waste = 60;       // RAYMARCH_PACK_WASTE: % of lane turns a partial last group may leave without a
                              // pass (their lanes still trace other lanes' secondary rays: 25 passes as
                              // 16 + 9 measured 12 % faster than as 6 x 4 + 1)
@@ -449,6 +451,15 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
       // (the same waste rule as choose_pass_pack: 32 slots only if at most pack_waste % of them stay without a pass)
       const bool one_of_32 = c->pass_pack_auto && run > 16 && run < 32 && 32.0 * 100.0 <= (100.0 + c->pack_waste) * run;
       pp_log2 = one_of_32 ? 5 : rmk::choose_pass_pack(run, c->pass_pack, c->pack_waste);
+      // THIN LAUNCHES (round 6): few tiles x few passes leave most of the chip's 28 wavefront slots per CU empty, and a frame
+      // then takes as long as its slowest wavefront.  Below 16 wavefronts per CU the pixels of a wavefront are halved (its
+      // other lanes hold no pass; they still trace the secondary rays of the lanes that do): 256 x 256 x 1 of a 256^3 volume
+      // 0.251 -> 0.162 ms, config 1 1.09 -> 0.85, 640 x 360 x 1 0.275 -> 0.217, 320 x 180 x 4 0.266 -> 0.227; 1280 x 720 x 1 and
+      // anything larger keeps its packing (r06_experiments.txt section 14).  Pixels do not depend on it.
+      if (c->pass_pack_auto && c->thin_wide) {
+        const long long tiles = rmk::tiles_per_part(rmk::tiles_total(resx, n), out.tile_stride);
+        while (pp_log2 < 4 && pp_log2 < c->pass_pack && (tiles << pp_log2) < 16ll * c->cus) pp_log2++;
+      }
     }
     i1 = std::min(run_end, i0 + (1 << pp_log2));  // one launch = what one wavefront holds
     const size_t acc_bytes = out.row_major ? (size_t)n * 16
@@ -569,6 +580,7 @@ static int create_one(int device_id, rm_ctx** out) {
   rm_ctx* c = new (std::nothrow) rm_ctx();
   if (!c) return fail(RM_EDEVICE, "out of host memory");
   c->device = device_id;
+  c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   for (int k = 0; k < 2 * rm_ctx::kTimingRing && e == hipSuccess; k++) e = hipEventCreate(&c->ev_ring[k]);
   c->ev0 = c->ev_ring[0];
@@ -616,8 +628,9 @@ static int create_one(int device_id, rm_ctx** out) {
   if (pk && atoi(pk) >= 0 && atoi(pk) <= 6) { c->pass_pack = atoi(pk); c->pass_pack_auto = false; }
   const char* bk = getenv("RAYMARCH_BRICKS");
   if (bk && (bk[0] == '0' || bk[0] == '1')) c->bricks = bk[0] - '0';
+  if (const char* tw = getenv("RAYMARCH_THIN")) c->thin_wide = tw[0] != '0';
   const char* pw = getenv("RAYMARCH_PACK_WASTE");
-  if (pw && atoi(pw) >= 0 && atoi(pw) <= 100) c->pack_waste = atoi(pw);
+  if (pw && atoi(pw) >= 0 && atoi(pw) <= 6400) c->pack_waste = atoi(pw);
   const char* p2 = getenv("RAYMARCH_POW2");
   if (p2) c->pow2_tables = p2[0] != '0';
   *out = c;

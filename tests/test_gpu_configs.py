@@ -163,7 +163,7 @@ def test_c5_1024_volume_1080p_25spp(native, oracle_mod):
     _check_against_oracle(oracle_mod, vox, opts, mc, n, ids, px, argb)
 
 
-def test_launches_continue_each_others_accumulators(native, oracle_mod):
+def test_launches_continue_each_others_accumulators(native, oracle_mod, monkeypatch):
     """A frame whose records change in the middle: 18 equal passes (8 + 8 + 2: a launch holds what one
     wavefront holds), one pass with another exposure, two passes with another isoVal (own tables) --
     five launches of the frame kernel, each continuing from the accumulator the previous one left,
@@ -176,11 +176,17 @@ def test_launches_continue_each_others_accumulators(native, oracle_mod):
         opts[i * 544 + 284] = 90                                      # isoVal of the last two
     opts = bytes(opts)
     want, want_argb = oracle_mod.render_frame(sc["vox"], opts, sc["mc"], sc["n"])
-    for ranks in (1, 3):
-        with native.Context([0] * ranks if ranks > 1 else 0) as ctx:
-            ctx.set_volume(sc["vox"], sc["vres"])
-            px, argb = ctx.render_frame(opts, sc["mc"], sc["n"])
-            ms, launches = ctx.last_frame_timing()
-        assert launches == 5
-        assert _eq(px, want), (ranks, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
-        assert np.array_equal(argb, want_argb)
+    # (a frame this small is a THIN launch: by default its wavefronts hold 16 passes of fewer pixels -- 16 + 2, four
+    #  launches; RAYMARCH_THIN=0 keeps the packing of a full-size frame)
+    for thin, expect in (("0", 5), (None, 4)):
+        monkeypatch.delenv("RAYMARCH_THIN", raising=False)
+        if thin is not None:
+            monkeypatch.setenv("RAYMARCH_THIN", thin)
+        for ranks in (1, 3):
+            with native.Context([0] * ranks if ranks > 1 else 0) as ctx:
+                ctx.set_volume(sc["vox"], sc["vres"])
+                px, argb = ctx.render_frame(opts, sc["mc"], sc["n"])
+                ms, launches = ctx.last_frame_timing()
+            assert launches == expect, (thin, ranks, launches)
+            assert _eq(px, want), (ranks, int((px.view(np.uint32) != want.view(np.uint32)).sum()))
+            assert np.array_equal(argb, want_argb)

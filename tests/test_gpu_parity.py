@@ -234,8 +234,9 @@ def test_passes_with_different_options_and_kernel_variants(oracle_mod, native, m
                 {"RAYMARCH_ROW_ORDER": "asc"}, {"RAYMARCH_ROW_ORDER": "asc", "RAYMARCH_PASS_PACK": "0"},
                 {"RAYMARCH_ROW_ORDER": "desc"}, {"RAYMARCH_ROW_ORDER": "band", "RAYMARCH_PASS_PACK": "1"},
                 {"RAYMARCH_XCD_2D": "0"}, {"RAYMARCH_XCD_2D": "1", "RAYMARCH_PASS_PACK": "0"},
-                {"RAYMARCH_XCD_2D": "0", "RAYMARCH_ROW_ORDER": "asc"}):
-        for k in ("RAYMARCH_NO_ACCEL", "RAYMARCH_POW2", "RAYMARCH_PASS_PACK", "RAYMARCH_OCTANTS",
+                {"RAYMARCH_XCD_2D": "0", "RAYMARCH_ROW_ORDER": "asc"}, {"RAYMARCH_THIN": "0"},
+                {"RAYMARCH_THIN": "0", "RAYMARCH_OCTANTS": "0"}, {"RAYMARCH_THIN": "0", "RAYMARCH_BRICKS": "1"}):
+        for k in ("RAYMARCH_NO_ACCEL", "RAYMARCH_POW2", "RAYMARCH_PASS_PACK", "RAYMARCH_OCTANTS", "RAYMARCH_THIN",
                   "RAYMARCH_XCD_ROWS", "RAYMARCH_BRICKS", "RAYMARCH_PACK_WASTE", "RAYMARCH_ROW_ORDER", "RAYMARCH_XCD_2D"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
