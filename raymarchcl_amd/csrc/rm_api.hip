@@ -505,6 +505,8 @@ int frame_on_device(rm_ctx* c, const RmOpts* d_opts, const float* d_mc, int resx
     f.pp_log2 = pp_log2;
     f.xcd_rows = c->xcd_rows;
     f.xcd_2d = c->xcd_2d_forced;  // (-1: the launcher picks the unit width, rm_kernels.hip frame_grid)
+    // (tables that no cache holds -- beyond 4 GiB, 1024^3 -- gain nothing from wide units: the narrowest that fill two CUs)
+    if (!sdf_frame && (size_t)c->vol->rx * c->vol->ry * c->vol->rz * 9 >= ((size_t)4 << 30)) f.unit_min_waves = 128;
     f.rows_desc = c->rows_desc;
     if (c->band_fixed_hi > c->band_fixed_lo) { f.band_lo = c->band_fixed_lo; f.band_hi = c->band_fixed_hi; }
     else if (c->rows_band && !sdf_frame) volume_band(host_recs[0], &f.band_lo, &f.band_hi);

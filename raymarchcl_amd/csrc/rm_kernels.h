@@ -44,6 +44,7 @@ struct FrameLaunch {
   int resx = 0, n = 0, passes = 0, tile_first = 0, tile_stride = 1;
   int pp_log2 = 0;
   bool xcd_rows = true, accumulate = false, row_major = false;
+  int unit_min_waves = 0;          // with xcd_2d < 0: wavefronts the narrowest 2-D unit must still hold (0: 448)
   int xcd_2d = -1;                 // with xcd_rows: 2-D units per XCD: 2 tile rows x 1/(8 n) of the row, n units per row pair (n = 1, 2, 4, 8); 0 = whole rows; -1 = chosen by the launcher
   bool rows_desc = true;           // with xcd_rows: tile rows dispatched bottom to top (the top rows -- sky -- make the shortest tail)
   // with rows_desc: the part of the image height (fractions, 0 = top) whose rows are dispatched FIRST -- the rows that can see

@@ -569,18 +569,19 @@ static long long frame_grid(const FrameLaunch& f, int* bpr_out, int* pp_log2_out
     if (bpr_out) *bpr_out = bpr;
     if (rows_out) { rows_out[0] = (int)rows; rows_out[1] = (int)groups; rows_out[2] = (int)share; rows_out[3] = 0; }
     // 2-D units: stripes must hold whole tiles.  Unit width 1/(8 nsu) of a row; auto (xcd_2d < 0): the narrowest unit that
-    // still holds at least half of the wavefronts an XCD has in flight (7 per SIMD x 4 x 32 CUs = 896) -- measured: config 2
-    // (640 wavefronts per unit at nsu = 1, 320 at 2) is fastest at 1, config 3 (960 / 480) at 2 (-4.6 % against 1), config 4
-    // (1920 / 960 / 480) within 0.4 % for 1 / 2 / 4, config 5 (1920 / 960) -1.2 .. -3 % against whole rows either way
+    // still holds unit_min_waves wavefronts -- by default half of what an XCD has in flight (7 per SIMD x 4 x 32 CUs = 896).
+    // Measured: config 2 (640 wavefronts per unit at nsu = 1, 320 at 2) is fastest at 1, config 3 (960 / 480) at 2 (-4.6 %
+    // against 1; 3 / 5 / 6: +2 / -0.4 / +0.2 %), config 4 (1920 / 960 / 480) within 0.4 % for 1 .. 6.  Narrow units balance the
+    // XCDs better, wide ones share more lines in an XCD's L2; a volume whose tables no cache holds (1024^3: 9 GiB) has only
+    // the first to gain and asks for 128: config 5 at nsu = 6 (160 wavefronts) 31.2 ms against 32.0-32.4 at 2
     {
       const int tpr = g.tiles_x / tile_stride;
       int nsu = f.xcd_2d;
       if (nsu < 0) {
         nsu = 0;
-        if (tpr % 8 == 0) {
-          nsu = 1;
-          while (nsu < 8 && tpr % (16 * nsu) == 0 && 2ll * (tpr / (16 * nsu)) * (1ll << pp_log2) >= 448) nsu *= 2;
-        }
+        const long long least = f.unit_min_waves > 0 ? f.unit_min_waves : 448;
+        for (int c = 1; c <= 8; ++c)
+          if (tpr % (8 * c) == 0 && (c == 1 || 2ll * (tpr / (8 * c)) * (1ll << pp_log2) >= least)) nsu = c;
       }
       if (nsu > 0 && tpr % (8 * nsu) == 0) {
         blocks = rows * bpr;

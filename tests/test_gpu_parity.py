@@ -346,7 +346,7 @@ def test_walk_limits_with_unusual_records(oracle_mod, native, name, over):
     assert ok.mean() > 0.5
 
 
-@pytest.mark.parametrize("w,h,spp", [(1280, 88, 2), (1024, 40, 16), (768, 24, 3)])
+@pytest.mark.parametrize("w,h,spp", [(1280, 88, 2), (1024, 40, 16), (768, 24, 3), (1920, 40, 4)])
 def test_frame_is_independent_of_the_xcd_unit_width(native, monkeypatch, w, h, spp):
     """The XCD-aware dispatch order (rm_kernels.hip frame_block) is a permutation of the launch's workgroups: whole tile
     rows per XCD, 2-D units of 1/8 .. 1/64 of a row pair, the width the launcher picks by itself and the plain block order
@@ -357,6 +357,7 @@ def test_frame_is_independent_of_the_xcd_unit_width(native, monkeypatch, w, h, s
     frames = {}
     for key, env in (("plain", {"RAYMARCH_XCD_ROWS": "0"}), ("auto", {}), ("0", {"RAYMARCH_XCD_2D": "0"}), ("1", {"RAYMARCH_XCD_2D": "1"}),
                      ("2", {"RAYMARCH_XCD_2D": "2"}), ("4", {"RAYMARCH_XCD_2D": "4"}), ("8", {"RAYMARCH_XCD_2D": "8"}),
+                     ("3", {"RAYMARCH_XCD_2D": "3"}), ("5", {"RAYMARCH_XCD_2D": "5"}), ("6", {"RAYMARCH_XCD_2D": "6"}),
                      ("2asc", {"RAYMARCH_XCD_2D": "2", "RAYMARCH_ROW_ORDER": "asc"})):
         for k in ("RAYMARCH_XCD_ROWS", "RAYMARCH_XCD_2D", "RAYMARCH_ROW_ORDER"):
             monkeypatch.delenv(k, raising=False)

@@ -173,15 +173,16 @@ def test_dispatch_order_of_the_frame_kernel_is_a_permutation(native):
                 for first in sorted({0, stride - 1}):
                     for kw in (dict(xcd_rows=False), dict(xcd_2d=0), dict(xcd_2d=0, rows_desc=False), dict(), dict(xcd_2d=1),
                                dict(xcd_2d=2), dict(xcd_2d=4), dict(xcd_2d=8, rows_desc=False), dict(band=(0.33, 0.83)),
+                               dict(xcd_2d=3), dict(xcd_2d=5, rows_desc=False), dict(xcd_2d=6),
                                dict(xcd_2d=0, band=(0.0, 0.5))):
-                        if big and kw.get("xcd_2d", -1) in (1, 8):
+                        if big and kw.get("xcd_2d", -1) in (1, 3, 8):
                             continue
                         blocks, padding = _check_block_order(native, w, h, passes, first, stride, **kw)
                         checked += 1
                         # the padding of the XCD-aware grid stays small next to a real frame
                         if w * h >= 640 * 360 and stride == 1:
                             assert padding <= 0.02 * blocks, (w, h, passes, kw, blocks, padding)
-    assert checked > 1500
+    assert checked > 2000
     # the 2-D units need no padding at all where they apply, and the launcher's own choice of the width applies to BASELINE's sizes
     for w, h in ((1280, 720), (1920, 1080), (3840, 2160)):
         order = native.block_order(w, w * h, 16)
