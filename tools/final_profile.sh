@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --lean > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 40 --warmup 5 --lean > $OUT/kt.log 2>&1
 DB=$(find /tmp/kt -name "*_results.db" | head -1)
 python $R/tools/rocprof_summary.py $DB > $OUT/kernel_stats.txt 2>&1
 cd $R
