@@ -102,3 +102,43 @@ def test_argb_only_frames_exchange_tonemapped_words(tmp_path, pin, world, frames
     _want, want_argb = pin.frame("metal_3spp", sc["vox"], sc["opts"], sc["mc"], sc["n"])
     assert not os.path.exists(tmp_path / "px.npy")
     assert np.array_equal(np.load(tmp_path / "argb.npy"), want_argb)
+
+
+def _rccl_one_rank(rank, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # bench.py's and _worker's call
+    ok = []
+    for stream in (torch.cuda.current_stream(dev), torch.cuda.Stream(dev)):  # one frame at a time / a slot's side stream
+        with torch.cuda.stream(stream):
+            # the collective exactly as multigpu.FrameRenderer._gather issues it on `nccl`: the root's receive buffer made
+            # once, its per-rank views as the gather list
+            mine = torch.arange(64 * 64 * 4, dtype=torch.float32, device=dev) * 0.5
+            d_all = torch.empty(1 * mine.numel(), dtype=mine.dtype, device=dev)
+            chunks = list(d_all.view(1, -1).unbind(0))
+            dist.gather(mine, gather_list=chunks, dst=0)
+            words = torch.arange(4096, dtype=torch.int32, device=dev)  # ARGB-only frames exchange int32 words
+            w_all = torch.empty(words.numel(), dtype=torch.int32, device=dev)
+            dist.gather(words, gather_list=list(w_all.view(1, -1).unbind(0)), dst=0)
+        stream.synchronize()
+        ok.append(bool(torch.equal(d_all, mine)) and bool(torch.equal(w_all, words)))
+    tt = torch.tensor([1.25], dtype=torch.float64, device=dev)  # bench.py: max over ranks of the elapsed time
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    ok.append(float(tt.item()) == 1.25)
+    with open(os.path.join(tmpdir, "ok.txt"), "w") as f:
+        f.write(" ".join(str(int(o)) for o in ok))
+    dist.destroy_process_group()
+
+
+def test_rccl_initialises_and_runs_the_renderers_collectives_on_one_rank(tmp_path):
+    """What CAN be executed of the RCCL side on a single-GPU box: the process group of bench.py / FrameRenderer comes up
+    on this box (`nccl` backend, device_id, the box's IPC mode) and the collectives the renderer issues -- gather into
+    views of one receive buffer, on the current and on a side stream; all-reduce MAX; barrier -- run on it.  The N > 1
+    exchange itself needs >= 2 devices (test_tile_partition_over_rccl)."""
+    mp.spawn(_rccl_one_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "ok.txt").read() == "1 1 1"
